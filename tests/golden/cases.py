@@ -1,0 +1,103 @@
+"""Deterministic synthetic inputs shared by the golden generator, the tests and bench.py.
+
+Argon Lennard-Jones clusters as SURVEY.md section 8(d) prescribes (so that the
+reference's own ``-os lj`` calculator accepts the same systems): simple-cubic
+lattice, 3.9 Angstrom spacing, Gaussian jitter.  Energies/gradients/Hessians are
+an analytic 12-6 LJ written here (Ar UFF parameters x = 3.817 A, D = 0.237 kcal/mol,
+the numbers quoted in SURVEY.md 8(d)); they are only a smooth test surface that
+feeds the reference, the oracle and the HIP path with identical numbers.
+"""
+import numpy as np
+
+BOHR2ANG = 0.52917721067
+_RMIN = 3.817 / BOHR2ANG            # bohr
+_EPS = 0.237 / 627.509              # hartree
+
+
+def cluster(N, seed_offset=0, jitter=0.15):
+    """N atoms (bohr) on a simple-cubic 3.9 A lattice + N(0, jitter A)."""
+    rng = np.random.default_rng(20240501 + N + seed_offset)
+    m = int(np.ceil(N ** (1.0 / 3.0)))
+    sites = np.array([(i, j, k) for i in range(m) for j in range(m) for k in range(m)], dtype=float)[:N]
+    x = sites * 3.9 + rng.normal(0.0, jitter, size=(N, 3))
+    return x / BOHR2ANG
+
+
+def band(I, N):
+    """I images (I,N,3) in bohr: cluster A -> A + smooth 0.6 A sine displacement along z (+ jitter)."""
+    A = cluster(N)
+    rng = np.random.default_rng(20240501 + N + 1)
+    L = (A[:, 0].max() - A[:, 0].min()) + 1.0
+    B = A.copy()
+    B[:, 2] += (0.6 / BOHR2ANG) * np.sin(2 * np.pi * A[:, 0] / L)
+    B += rng.normal(0.0, 0.05 / BOHR2ANG, size=B.shape)
+    t = np.linspace(0.0, 1.0, I)[:, None, None]
+    return (1 - t) * A[None] + t * B[None]
+
+
+def lj(x, hessian=False):
+    """12-6 LJ energy (hartree), gradient (N,3) and optionally Hessian (3N,3N)."""
+    x = np.asarray(x, dtype=float).reshape(-1, 3)
+    N = x.shape[0]
+    d = x[:, None, :] - x[None, :, :]
+    r2 = np.sum(d * d, axis=2)
+    np.fill_diagonal(r2, 1.0)
+    s2 = _RMIN ** 2 / r2
+    s6 = s2 ** 3
+    s12 = s6 ** 2
+    e_pair = _EPS * (s12 - 2 * s6)
+    np.fill_diagonal(e_pair, 0.0)
+    E = 0.5 * np.sum(e_pair)
+    # dE/dr * 1/r
+    f = _EPS * (-12 * s12 + 12 * s6) / r2
+    np.fill_diagonal(f, 0.0)
+    G = np.sum(f[:, :, None] * d, axis=1)
+    if not hessian:
+        return E, G
+    # second derivative pieces: phi'' and phi'/r
+    h2 = _EPS * (156 * s12 - 84 * s6) / r2          # phi''
+    np.fill_diagonal(h2, 0.0)
+    H = np.zeros((3 * N, 3 * N))
+    for a in range(N):
+        for b in range(N):
+            if a == b:
+                continue
+            dd = d[a, b]
+            blk = (h2[a, b] - f[a, b]) * np.outer(dd, dd) / r2[a, b] + f[a, b] * np.eye(3)
+            H[3 * a:3 * a + 3, 3 * b:3 * b + 3] -= blk
+            H[3 * a:3 * a + 3, 3 * a:3 * a + 3] += blk
+    return E, G, H
+
+
+def spd_matrix(n, seed=0, indefinite=False):
+    """H = A A^T / n + 0.1 I  (SURVEY 8(d) micro-benchmark matrix); optional sign flips."""
+    rng = np.random.default_rng(seed)
+    A = rng.normal(size=(n, n))
+    H = A @ A.T / n + 0.1 * np.eye(n)
+    if indefinite:
+        w, v = np.linalg.eigh(H)
+        w[:3] *= -1.0
+        H = (v * w) @ v.T
+        H = 0.5 * (H + H.T)
+    return H
+
+
+def sy_pair(H, seed=1, kind="normal"):
+    """(s, y) pairs incl. the edge cases the update rules branch on."""
+    n = H.shape[0]
+    rng = np.random.default_rng(seed)
+    s = 0.01 * rng.normal(size=n)
+    if kind == "normal":
+        y = H @ s + 0.002 * rng.normal(size=n)
+    elif kind == "negative":          # s.y < 0
+        y = -(H @ s) + 0.0005 * rng.normal(size=n)
+    elif kind == "dd":                # 0 < s.y < 0.2 s.s -> damping active
+        y = 0.05 * s + 1e-4 * rng.normal(size=n)
+    elif kind == "tiny":              # denominators below 1e-10
+        s = 1e-7 * rng.normal(size=n)
+        y = 1e-7 * rng.normal(size=n)
+    elif kind == "exact":             # y = H s: A = 0
+        y = H @ s
+    else:
+        raise ValueError(kind)
+    return s, y

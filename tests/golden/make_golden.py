@@ -1,0 +1,371 @@
+"""Generate the golden vectors by IMPORTING the reference (build container only).
+
+Usage:  python tests/golden/make_golden.py        (needs /root/reference, read-only)
+
+The reference is loaded through a package shim that bypasses
+multioptpy/__init__.py (which imports ASE unguarded).  Nothing
+from the reference is copied: only inputs and the outputs it computes are stored,
+as small .npz files next to this script.  The reference never travels to the GPU
+box; tests read only the .npz files.
+"""
+import contextlib
+import io
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import cases  # noqa: E402
+
+REF = "/root/reference/multioptpy"
+
+
+def load_reference():
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.dont_write_bytecode = True
+    pkg = types.ModuleType("multioptpy")
+    pkg.__path__ = [REF]
+    sys.modules["multioptpy"] = pkg
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+# every dispatch key of rsirfo.py:208-251 plus an unknown name (falls back to flowchart)
+UPDATE_METHODS = [
+    "rsirfo_flowchart", "rsirfo_block_cfd_fsb_dd", "rsirfo_block_cfd_fsb_weighted", "rsirfo_block_cfd_fsb",
+    "rsirfo_block_cfd_bofill_weighted", "rsirfo_block_cfd_bofill", "rsirfo_block_bfgs_dd", "rsirfo_block_bfgs",
+    "rsirfo_block_fsb_dd", "rsirfo_block_fsb_weighted", "rsirfo_block_fsb", "rsirfo_block_bofill_weighted",
+    "rsirfo_block_bofill", "rsirfo_bfgs_dd", "rsirfo_bfgs", "rsirfo_sr1", "rsirfo_pcfd_bofill", "rsirfo_cfd_fsb_dd",
+    "rsirfo_cfd_fsb", "rsirfo_cfd_bofill", "rsirfo_fsb_dd", "rsirfo_fsb", "rsirfo_bofill", "rsirfo_psb", "rsirfo_msp",
+    "rsirfo_auto",
+]
+
+
+def g1_updates():
+    """G1: delta_H of every rule through RSIRFO's own dispatch list."""
+    from multioptpy.Optimizer import rsirfo
+    out = {}
+    idx = 0
+    for n in (21, 42):
+        for indef in (False, True):
+            H = cases.spd_matrix(n, seed=n + int(indef), indefinite=indef)
+            for kind in ("normal", "negative", "dd", "tiny", "exact"):
+                sd = 7 * n + idx
+                s, y = cases.sy_pair(H, seed=sd, kind=kind)
+                for m in UPDATE_METHODS:
+                    opt = rsirfo.RSIRFO(method=m, saddle_order=0)
+                    low = m.lower()
+                    fn = opt.default_update_method[1]
+                    for key, _, f in opt.updater_dispatch_list:
+                        if key in low:
+                            fn = f
+                            break
+                    with quiet():
+                        d = fn(H.copy(), s.reshape(-1, 1).copy(), y.reshape(-1, 1).copy())
+                    tag = f"c{idx:03d}"
+                    out[tag + "_meta"] = np.array([n, int(indef), sd])
+                    out[tag + "_kind"] = np.array(kind)
+                    out[tag + "_method"] = np.array(m)
+                    out[tag + "_delta"] = np.asarray(d, dtype=float)
+                    idx += 1
+    np.savez_compressed(os.path.join(HERE, "g1_updates.npz"), **out)
+    print("G1:", idx, "cases")
+
+
+def _trace_rsirfo(cls_module, method, saddle_order, N, nsteps, neb_mode, h0_kind, seed, out, tag):
+    """Drive consecutive RSIRFO.run calls along an LJ surface, record inputs + outputs."""
+    import scipy.optimize
+    rsirfo = cls_module
+    x = cases.cluster(N, seed_offset=seed)
+    n = 3 * N
+    E, G, Hx = cases.lj(x, hessian=True)
+    if h0_kind == "exact":
+        H = Hx.copy()
+    elif h0_kind == "identity":
+        H = np.eye(n)
+    else:
+        H = cases.spd_matrix(n, seed=seed)
+    opt = rsirfo.RSIRFO(method=method, saddle_order=saddle_order, trust_radius_max=0.5 if saddle_order == 0 else 0.1,
+                        trust_radius_min=0.01)
+    if neb_mode:
+        opt.switch_NEB_mode()
+    brent_calls = []
+    real_brentq = scipy.optimize.brentq
+
+    def wrapped_brentq(f, a, b, **kw):
+        evals = []
+
+        def g(z):
+            v = f(z)
+            evals.append((float(z), float(v)))
+            return v
+        r = real_brentq(g, a, b, **kw)
+        brent_calls.append((np.array(evals), float(r)))
+        return r
+    rsirfo.brentq = wrapped_brentq
+    solve_log = []
+    real_solve = rsirfo.RSIRFO.solve_rfo
+
+    def wrapped_solve(self, eigvals, gc, alpha, mode="min"):
+        r = real_solve(self, eigvals, gc, alpha, mode)
+        solve_log.append((float(alpha), float(r[1])))
+        return r
+    rsirfo.RSIRFO.solve_rfo = wrapped_solve
+    try:
+        px = pg = pE = None
+        out[tag + "_meta"] = np.array([N, saddle_order, int(neb_mode), nsteps, seed])
+        out[tag + "_method"] = np.array(method)
+        out[tag + "_h0kind"] = np.array(h0_kind)
+        out[tag + "_H0"] = H.copy() if n <= 66 else np.zeros(0)
+        for k in range(nsteps):
+            E, G = cases.lj(x)
+            g = G.reshape(-1, 1)
+            xx = x.reshape(-1, 1).copy()
+            opt.set_hessian(H)               # optmain re-sets the same array every step (F7)
+            opt.set_bias_hessian(np.zeros((n, n)))
+            del brent_calls[:]
+            del solve_log[:]
+            with quiet():
+                if k == 0:
+                    step = opt.run(xx, g, [], [], E, 0.0, [], [], g, [])
+                else:
+                    step = opt.run(xx, g, pg, px, E, pE, [], [], g, pg)
+            out[f"{tag}_s{k}_x"] = xx.copy()
+            out[f"{tag}_s{k}_g"] = g.copy()
+            out[f"{tag}_s{k}_E"] = np.array(E)
+            out[f"{tag}_s{k}_step"] = np.asarray(step).copy()
+            out[f"{tag}_s{k}_tr"] = np.array(opt.trust_radius)
+            out[f"{tag}_s{k}_pred"] = np.array(opt.predicted_energy_changes[-1])
+            out[f"{tag}_s{k}_solve"] = np.array(solve_log).reshape(-1, 2)
+            if brent_calls:
+                out[f"{tag}_s{k}_brent_evals"] = brent_calls[0][0]
+                out[f"{tag}_s{k}_brent_root"] = np.array(brent_calls[0][1])
+            if n <= 66 or k == nsteps - 1:
+                out[f"{tag}_s{k}_Hself"] = np.array(opt.hessian).copy()
+                out[f"{tag}_s{k}_Hcaller"] = H.copy()
+            px, pg, pE = xx, g, E
+            x = (xx - step).reshape(-1, 3)
+    finally:
+        rsirfo.brentq = real_brentq
+        rsirfo.RSIRFO.solve_rfo = real_solve
+
+
+def g2_rsirfo():
+    """G2 (+G4 brentq traces): consecutive RSIRFO.run calls."""
+    from multioptpy.Optimizer import rsirfo
+    out = {}
+    cfgs = []
+    for N, nst in ((7, 4), (11, 4), (22, 4)):
+        for so in (0, 1):
+            for method in ("rsirfo_bfgs", "rsirfo_fsb", "rsirfo_bofill", "rsirfo_block_fsb", "rsirfo_block_bofill"):
+                cfgs.append((method, so, N, nst, False, "exact", 0))
+    cfgs.append(("rsirfo_block_bofill", 0, 7, 4, True, "identity", 1))
+    cfgs.append(("rsirfo_block_bofill", 1, 7, 4, True, "exact", 2))
+    cfgs.append(("rsirfo_block_fsb", 0, 14, 5, False, "identity", 3))
+    cfgs.append(("rsirfo_bfgs", 0, 11, 4, False, "spd", 4))
+    cfgs.append(("rsirfo_bfgs", 0, 100, 3, False, "exact", 5))
+    cfgs.append(("rsirfo_block_bofill", 0, 100, 3, True, "identity", 6))
+    for i, c in enumerate(cfgs):
+        _trace_rsirfo(rsirfo, c[0], c[1], c[2], c[3], c[4], c[5], c[6], out, f"t{i:02d}")
+    out["ncfg"] = np.array(len(cfgs))
+    np.savez_compressed(os.path.join(HERE, "g2_rsirfo.npz"), **out)
+    print("G2:", len(cfgs), "traces")
+
+
+def g5_projections():
+    from multioptpy.Optimizer import rsirfo
+    from multioptpy.Utils.calc_tools import Calculationtools
+    out = {}
+    geoms = {
+        "ar7": cases.cluster(7),
+        "ar22": cases.cluster(22),
+        "linear_z": np.array([[0, 0, -2.0], [0, 0, 0.0], [0, 0, 2.5]]),
+        "diatomic": np.array([[0.1, 0.2, 0.3], [1.5, -0.4, 0.9]]),
+    }
+    opt = rsirfo.RSIRFO(method="rsirfo_bfgs", saddle_order=0)
+    for name, x in geoms.items():
+        n = x.size
+        H = cases.spd_matrix(n, seed=n)
+        rng = np.random.default_rng(n)
+        g = rng.normal(size=n)
+        with quiet():
+            Hp = Calculationtools().project_out_hess_tr_and_rot_for_coord(H, x.copy(), x.copy(), False)
+            gp = opt._project_grad_tr_rot(g.copy(), x.reshape(-1, 1).copy())
+        out[name + "_x"] = x
+        out[name + "_H"] = H
+        out[name + "_g"] = g
+        out[name + "_Hp"] = Hp
+        out[name + "_gp"] = gp
+    P = cases.cluster(9)
+    rng = np.random.default_rng(3)
+    Q = P + 0.05 * rng.normal(size=P.shape)
+    th = 0.3
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    Q = Q @ R.T + 0.7
+    Pk, Qk = Calculationtools().kabsch_algorithm(P.copy(), Q.copy())
+    out["kabsch_P"], out["kabsch_Q"], out["kabsch_Pout"], out["kabsch_Qout"] = P, Q, Pk, Qk
+    np.savez_compressed(os.path.join(HERE, "g5_projections.npz"), **out)
+    print("G5 done")
+
+
+def _band_inputs(I, N, bump):
+    X = cases.band(I, N)
+    E = np.zeros(I)
+    G = np.zeros((I, N, 3))
+    for i in range(I):
+        E[i], G[i] = cases.lj(X[i])
+    # optional synthetic energy profile to visit all three tangent cases
+    if bump is not None:
+        E = E + np.asarray(bump)
+    return X, E, G
+
+
+def g6_neb_forces():
+    from multioptpy.MEP import pathopt_bneb_force as bf
+    out = {}
+    k = 0
+    for N in (7, 14):
+        for bump in (None, [0, 1e-3, 2e-3, 1.5e-3, 1e-3, 1.2e-3, 2.5e-3, 0.5e-3], [0, -1e-3, -2e-3, -3e-3, -2e-3, -1e-3, 0, 1e-3]):
+            for ci in (False, True):
+                X, E, G = _band_inputs(8, N, bump)
+                if k % 3 == 1:
+                    X[3, 2] = X[2, 2]          # zero displacement of one atom between neighbours
+                calc = bf.CaluculationBNEB(APPLY_CI_NEB=(2 if ci else 99999))
+                with quiet():
+                    F = calc.calc_force(X.copy(), E.copy(), G.copy(), 5, ["Ar"] * N)
+                tau = np.array(calc.tau_list)
+                gam = np.zeros(8)
+                for i in range(1, 7):
+                    gam[i] = calc.calculate_gamma(X[i - 1:i + 2], E[i - 1:i + 2], G[i - 1:i + 2], calc.get_tau(i))
+                tag = f"f{k:02d}"
+                out[tag + "_X"], out[tag + "_E"], out[tag + "_G"] = X, E, G
+                out[tag + "_ci"] = np.array(int(ci))
+                out[tag + "_F"], out[tag + "_tau"], out[tag + "_gamma"] = F, tau, gam
+                k += 1
+    out["ncase"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "g6_neb_force.npz"), **out)
+    print("G6:", k, "cases")
+
+
+BRENT_FUNCS = {
+    "cubic": (lambda t: t ** 3 - 2 * t - 5, 2.0, 3.0),
+    "cosx": (lambda t: np.cos(t) - t, 0.0, 1.0),
+    "recip": (lambda t: 1.0 / t - 5.0, 1e-6, 1000.0),
+    "steep": (lambda t: np.tanh(40 * (t - 0.3)) + 0.2, 1e-6, 1000.0),
+    "norm2": (lambda t: 0.81 / (1 + t) ** 2 - 0.25, 1e-6, 1000.0),
+}
+
+
+def g4_brentq():
+    """G4: every (x, f(x)) that the real scipy.optimize.brentq evaluates, with the call-site tolerances
+    of rsirfo.py:1042 (xtol = rtol = 1e-6, maxiter = 50) and with tight ones."""
+    import scipy.optimize
+    out = {}
+    for name, (f, a, b) in BRENT_FUNCS.items():
+        for tname, kw in (("loose", dict(xtol=1e-6, rtol=1e-6, maxiter=50)), ("tight", dict(xtol=1e-12, rtol=1e-12, maxiter=100))):
+            ev = []
+
+            def g(t, f=f, ev=ev):
+                v = f(t)
+                ev.append((float(t), float(v)))
+                return v
+            r = scipy.optimize.brentq(g, a, b, **kw)
+            out[f"{name}_{tname}_evals"] = np.array(ev)
+            out[f"{name}_{tname}_root"] = np.array(r)
+    out["scipy_version"] = np.array(scipy.__version__)
+    np.savez_compressed(os.path.join(HERE, "g4_brentq.npz"), **out)
+    print("G4 done, scipy", scipy.__version__)
+
+
+class _Cfg:
+    pass
+
+
+def g7_neb_step():
+    """G7: TR_calc, FIRE and RFOOptimizer.optimize over consecutive band steps (I=8, N=7)."""
+    from multioptpy.MEP import pathopt_bneb_force as bf
+    from multioptpy.Optimizer import rfo_neb, fire_neb, trust_radius_neb
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="mopt_g7_") + "/"
+    cfg = _Cfg()
+    cfg.NEB_FOLDER_DIRECTORY = tmp
+    cfg.fix_init_edge = False
+    cfg.fix_end_edge = False
+    cfg.apply_convergence_criteria = False
+    cfg.ratio_of_rfo_step = 0.5
+    cfg.bohr2angstroms = cases.BOHR2ANG
+    cfg.dt, cfg.a, cfg.n_reset = 0.5, 0.10, 0
+    cfg.FIRE_N_accelerate, cfg.FIRE_f_inc, cfg.FIRE_f_accelerate = 5, 1.10, 0.99
+    cfg.FIRE_f_decelerate, cfg.FIRE_a_start, cfg.FIRE_dt_max = 0.5, 0.1, 1.0
+    I, N = 8, 7
+    cfg.element_list = ["Ar"] * N
+    for variant, exact in (("ident", False), ("exact", True)):
+        for f in os.listdir(tmp):
+            os.remove(tmp + f)
+        X = cases.band(I, N)
+        if exact:
+            for i in range(I):
+                np.save(tmp + f"tmp_hessian_{i}.npy", cases.lj(X[i], hessian=True)[2])
+        calc = bf.CaluculationBNEB()
+        optm = rfo_neb.RFOOptimizer(cfg)
+        preX = preG = None
+        pre_vel = []
+        for it in range(4):
+            E = np.zeros(I)
+            G = np.zeros((I, N, 3))
+            for i in range(I):
+                E[i], G[i] = cases.lj(X[i])
+            with quiet():
+                F = calc.calc_force(X, E, G, it, cfg.element_list)
+                vel = np.array(F, dtype=float)
+                newX = optm.optimize(X, G, preX, preG, it, E, E, pre_vel, vel, None, preX, calc)
+            tag = f"{variant}_it{it}"
+            out[tag + "_X"], out[tag + "_E"], out[tag + "_G"], out[tag + "_F"] = X.copy(), E, G, F
+            out[tag + "_newX"] = np.array(newX)
+            out[tag + "_hess"] = np.array([np.load(tmp + f"tmp_hessian_{i}.npy") for i in range(I)])
+            out[tag + "_tr"] = np.array([o.trust_radius for o in optm.optimizer_instance_list])
+            preX, preG, pre_vel = X.copy(), G.copy(), vel.copy()
+            X = np.array(newX) / cases.BOHR2ANG
+    # standalone TR_calc and FIRE on fixed inputs
+    X = cases.band(I, N)
+    rng = np.random.default_rng(11)
+    Fr = 0.01 * rng.normal(size=X.shape)
+    delta = [0.3 * rng.normal(size=(N, 3)) * (0.02 + 0.2 * (i % 3)) for i in range(I)]
+    trn = trust_radius_neb.TR_NEB(NEB_FOLDER_DIRECTORY=tmp)
+    with quiet():
+        mv = trn.TR_calc(X, Fr, [d.copy() for d in delta], None, None, None)
+    out["tr_X"], out["tr_F"], out["tr_delta"], out["tr_out"] = X, Fr, np.array(delta), np.array(mv)
+    fo = fire_neb.FIREOptimizer(cfg)
+    vel = 0.01 * rng.normal(size=X.shape)
+    pre_vel = 0.01 * rng.normal(size=X.shape)
+    with quiet():
+        nx = fo.optimize(X, Fr, pre_vel, 3, vel, None, None, None, None)
+    out["fire_vel"], out["fire_prevel"], out["fire_out"] = vel, pre_vel, np.array(nx)
+    out["fire_state"] = np.array([fo.dt, fo.a, fo.n_reset])
+    np.savez_compressed(os.path.join(HERE, "g7_neb_step.npz"), **out)
+    print("G7 done")
+
+
+if __name__ == "__main__":
+    load_reference()
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7"]
+    if "g1" in which:
+        g1_updates()
+    if "g2" in which:
+        g2_rsirfo()
+    if "g4" in which:
+        g4_brentq()
+    if "g5" in which:
+        g5_projections()
+    if "g6" in which:
+        g6_neb_forces()
+    if "g7" in which:
+        g7_neb_step()
