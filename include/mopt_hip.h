@@ -1,0 +1,187 @@
+/*
+ * mopt_hip.h -- C ABI of libmopt_hip.so: MI355X (gfx950) kernels for the MultiOptPy
+ * optimizer-step hot path.
+ *
+ * The reference (ss0832/MultiOptPy) is pure Python and has no FFI; its boundary for this
+ * path is the duck-typed Optimizer plugin surface.  Each entry point
+ * below names the reference interface it stands in for (file:line relative to
+ * /root/reference).  multioptpy_amd/ binds these with ctypes and re-exposes the
+ * reference's own class/method names on top.
+ *
+ * Conventions: extern "C"; every function returns 0 on success and a negative MOPT_E_*
+ * code otherwise (mopt_last_error gives the text); no exceptions cross the boundary;
+ * all floating point data is IEEE double, C-contiguous row-major; n = 3*N; host
+ * pointers unless the name says "dev"; one mopt_ctx per device, calls on one ctx are
+ * stream-ordered and must not be issued concurrently from several threads.
+ */
+#ifndef MOPT_HIP_H
+#define MOPT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOPT_ABI_VERSION 1
+
+enum {
+    MOPT_OK = 0,
+    MOPT_E_ARG = -1,      /* bad argument (null pointer, size out of range, unknown rule) */
+    MOPT_E_DEVICE = -2,   /* HIP runtime error (text in mopt_last_error) */
+    MOPT_E_NOMEM = -3,
+    MOPT_E_STATE = -4     /* call sequence error (e.g. Hessian not set) */
+};
+
+/* Hessian update rules = the dispatch keys of multioptpy/Optimizer/rsirfo.py:208-251 in
+ * priority order; MOPT_RULE_FLOWCHART is also the fall-back for unknown names. */
+enum {
+    MOPT_RULE_FLOWCHART = 0,
+    MOPT_RULE_BLOCK_CFD_FSB_DD, MOPT_RULE_BLOCK_CFD_FSB_WEIGHTED, MOPT_RULE_BLOCK_CFD_FSB,
+    MOPT_RULE_BLOCK_CFD_BOFILL_WEIGHTED, MOPT_RULE_BLOCK_CFD_BOFILL,
+    MOPT_RULE_BLOCK_BFGS_DD, MOPT_RULE_BLOCK_BFGS,
+    MOPT_RULE_BLOCK_FSB_DD, MOPT_RULE_BLOCK_FSB_WEIGHTED, MOPT_RULE_BLOCK_FSB,
+    MOPT_RULE_BLOCK_BOFILL_WEIGHTED, MOPT_RULE_BLOCK_BOFILL,
+    MOPT_RULE_BFGS_DD, MOPT_RULE_BFGS, MOPT_RULE_SR1, MOPT_RULE_PCFD_BOFILL,
+    MOPT_RULE_CFD_FSB_DD, MOPT_RULE_CFD_FSB, MOPT_RULE_CFD_BOFILL,
+    MOPT_RULE_FSB_DD, MOPT_RULE_FSB, MOPT_RULE_BOFILL, MOPT_RULE_PSB, MOPT_RULE_MSP,
+    MOPT_RULE_COUNT
+};
+
+typedef struct mopt_ctx mopt_ctx;
+
+/* ---- context ------------------------------------------------------------------------ */
+int mopt_abi_version(void);
+int mopt_ctx_create(int device, mopt_ctx **out);
+int mopt_ctx_destroy(mopt_ctx *ctx);
+const char *mopt_last_error(const mopt_ctx *ctx);
+int mopt_ctx_sync(mopt_ctx *ctx);
+/* milliseconds spent in the named kernel family since the last reset, measured with HIP
+ * events on the ctx stream when timing is enabled (bench.py roofline leg). */
+int mopt_ctx_timing(mopt_ctx *ctx, int enable);
+int mopt_ctx_timing_read(mopt_ctx *ctx, const char *family, double *ms, int64_t *launches);
+
+/* ---- building blocks (batched over `batch` independent matrices) ---------------------- */
+
+/* Quasi-Newton update.  Stands in for ModelHessianUpdate.* / BlockHessianUpdate.block_*
+ * (multioptpy/Optimizer/hessian_update.py:163-433, block_hessian_update.py:443-709) as
+ * driven by RSIRFO.update_hessian (rsirfo.py:1316-1372), including its guards
+ * (|s|,|y| < 1e-10 or s.y <= 0 -> no update).
+ *   H        in : batch x n x n
+ *   s, y     in : batch x n        (displacement, gradient difference)
+ *   H_inplace out: H + delta  (what the caller's aliased array holds after `+=`), may be NULL
+ *   H_sym     out: 0.5 * (X + X^T) of the above (the optimizer's new self.hessian)
+ *   info      out: batch x 8 doubles {applied, s.y, s.s, y.y, s.Hs, phi2/weight, branch, 0}, may be NULL */
+int mopt_hess_update(mopt_ctx *ctx, int rule, int n, int batch, const double *H, const double *s,
+                     const double *y, double *H_inplace, double *H_sym, double *info);
+
+/* Calculationtools.project_out_hess_tr_and_rot_for_coord (multioptpy/Utils/calc_tools.py:249-316):
+ * Hp = sym(P^T H P), P = I - sum v v^T over the Gram-Schmidt'ed translation/rotation vectors. */
+int mopt_project_trrot_hess(mopt_ctx *ctx, int n, int batch, const double *H, const double *X, double *Hp);
+
+/* RSIRFO._project_grad_tr_rot (multioptpy/Optimizer/rsirfo.py:128-190): g - Q Q^T g, Q = reduced
+ * Householder QR of the (n,6) translation/rotation matrix. */
+int mopt_project_trrot_grad(mopt_ctx *ctx, int n, int batch, const double *g, const double *X, double *gp);
+
+/* numpy.linalg.eigh as called at rsirfo.py:606,626,652: A symmetric (batch x n x n),
+ * W ascending (batch x n), V (batch x n x n) with eigenvectors in COLUMNS (V[:, i]).
+ * sweeps_out (may be NULL) receives the Jacobi sweep count per matrix. */
+int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, double *W, double *V, int *sweeps_out);
+
+/* ---- RSIRFO.run (multioptpy/Optimizer/rsirfo.py:285-490), batched ---------------------- */
+
+typedef struct mopt_rsirfo_params {
+    /* constructor configuration, rsirfo.py:26-91 */
+    double alpha0, alpha_max, alpha_step_max;
+    double small_eigval_thresh;
+    double trust_radius_min, trust_radius_max;
+    double good_step_threshold, poor_step_threshold;
+    double trust_radius_increase_factor, trust_radius_decrease_factor;
+    double energy_change_threshold, gradient_norm_threshold, step_norm_tolerance;
+    double adaptive_trust_gradient_norm_threshold;
+    double max_curvature_factor, negative_curvature_safety;
+    double level_shift_value, condition_number_threshold;
+    int32_t max_micro_cycles;
+    int32_t saddle_order;
+    int32_t rule;                 /* MOPT_RULE_* */
+    int32_t use_adaptive_trust_radius;
+    int32_t use_level_shift, auto_level_shift;
+    int32_t neb_mode;
+    int32_t reserved;
+} mopt_rsirfo_params;
+
+typedef struct mopt_rsirfo_state {
+    /* the mutable attributes RSIRFO keeps between calls */
+    double trust_radius;
+    double prev_energy;
+    double predicted[3];          /* predicted_energy_changes (last <= 3) */
+    double actual[3];             /* actual_energy_changes   (last <= 3) */
+    int32_t n_predicted, n_actual;
+    int32_t has_prev;             /* prev_geometry/prev_gradient/prev_energy are set */
+    int32_t iteration;
+    int32_t converged;
+    int32_t prev_eigvec_size;     /* -1 = None */
+    int32_t level_shift_applied;
+    /* diagnostics of the last call (not inputs) */
+    int32_t branch;               /* 0 within radius, 1 brent, 2 newton loop, 3 steepest-descent fallback */
+    int32_t hess_updated;
+    int32_t n_kept;               /* eigenpairs after the 1e-6 filter */
+    int32_t jacobi_sweeps;
+    int32_t secular_iters;
+    double alpha, lambda_aug, initial_step_norm, gradient_norm;
+} mopt_rsirfo_state;
+
+/* One RSIRFO.run for `batch` independent geometries (images).
+ *   hessian      in : batch x n x n   (self.hessian)
+ *   bias_hessian in : batch x n x n or NULL (self.bias_hessian is None)
+ *   geom         in : batch x n       geom_num_list (bohr)
+ *   B_g          in : batch x n       biased gradient (used for the step)
+ *   g            in : batch x n       raw gradient (used for the Hessian update)
+ *   pre_geom/pre_g in: batch x n or NULL (no history: first call)
+ *   B_e          in : batch           biased energy
+ *   step        out : batch x n       the value run() returns (to be SUBTRACTED by the caller)
+ *   H_inplace   out : batch x n x n or NULL   (caller-aliased array after `+=`, F7)
+ *   H_sym       out : batch x n x n   (new self.hessian; equals `hessian` when no update happened)
+ * params: one struct per image; state: one struct per image, in/out. */
+int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *params,
+                    mopt_rsirfo_state *state, const double *hessian, const double *bias_hessian,
+                    const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                    const double *pre_g, const double *B_e, double *step, double *H_inplace, double *H_sym);
+
+/* ---- NEB band ------------------------------------------------------------------------ */
+
+/* CaluculationBNEB.calc_force (multioptpy/MEP/pathopt_bneb_force.py:33-65) for I images of N atoms.
+ *   X, G : I x N x 3, E : I;  F, tau out: I x N x 3 (tau = tau_list, pathopt_bneb_force.py:60)
+ *   optimize_num, apply_ci_neb: the CI-NEB switch `optimize_num > APPLY_CI_NEB` (:50-55). */
+int mopt_bneb_force(mopt_ctx *ctx, int I, int N, const double *X, const double *E, const double *G,
+                    int optimize_num, int apply_ci_neb, double *F, double *tau);
+
+/* Device-resident band: the per-image Hessians and RSIRFO instances of RFOOptimizer
+ * (multioptpy/Optimizer/rfo_neb.py:86-208) stay in HBM between steps instead of going
+ * through tmp_hessian_{i}.npy (rfo_neb.py:18-25,175). */
+typedef struct mopt_band mopt_band;
+
+int mopt_band_create(mopt_ctx *ctx, int I, int N, mopt_band **out);
+int mopt_band_destroy(mopt_band *band);
+/* image-sharded use: this rank owns images [first, first+count) of a band of I images. */
+int mopt_band_set_shard(mopt_band *band, int first, int count);
+/* H = NULL -> identity (rfo_neb.py:25). */
+int mopt_band_set_hessian(mopt_band *band, int image, const double *H);
+int mopt_band_get_hessian(mopt_band *band, int image, double *H);
+int mopt_band_get_state(mopt_band *band, int image, mopt_rsirfo_state *out);
+/* options: ratio_of_rfo_step (rfo_neb.py:98), fix_init_edge / fix_end_edge (trust_radius_neb.py:7-8),
+ * apply_ts_opt (rfo_neb.py:97), APPLY_CI_NEB (pathopt_bneb_force.py:22). */
+int mopt_band_configure(mopt_band *band, double ratio_of_rfo_step, int fix_init_edge, int fix_end_edge,
+                        int apply_ts_opt, int apply_ci_neb);
+/* Copy one step's inputs to HBM: X, G : I x N x 3 (bohr, hartree/bohr), E : I. */
+int mopt_band_upload(mopt_band *band, const double *X, const double *E, const double *G);
+/* RFOOptimizer.optimize (rfo_neb.py:104-208) on the uploaded inputs: BNEB force, Ayala curvature,
+ * per-image RSIRFO.run, step limit, TR_calc, FIRE, blend.  Leaves the new geometry (Angstrom, as
+ * the reference returns it) on the device; the previous inputs become pre_geom / pre_gradient. */
+int mopt_band_step(mopt_band *band, int optimize_num);
+int mopt_band_download(mopt_band *band, double *newX_angstrom, double *F, double *rfo_step);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPT_HIP_H */
