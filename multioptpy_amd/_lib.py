@@ -1,0 +1,108 @@
+"""Loader for libmopt_hip.so (the C ABI of include/mopt_hip.h).  There is no CPU fallback:
+if the library is missing or no MI355X is visible, every entry point raises."""
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+from . import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmopt_hip.so")
+
+DP = C.POINTER(C.c_double)
+IP = C.POINTER(C.c_int)
+
+
+class MoptError(RuntimeError):
+    pass
+
+
+_lib = None
+_ctx = {}
+_lock = threading.Lock()
+
+
+def _proto(lib):
+    vp = C.c_void_p
+    lib.mopt_abi_version.restype = C.c_int
+    lib.mopt_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.mopt_ctx_destroy.argtypes = [vp]
+    lib.mopt_last_error.argtypes = [vp]
+    lib.mopt_last_error.restype = C.c_char_p
+    lib.mopt_ctx_sync.argtypes = [vp]
+    lib.mopt_ctx_timing.argtypes = [vp, C.c_int]
+    lib.mopt_ctx_timing_read.argtypes = [vp, C.c_char_p, DP, C.POINTER(C.c_int64)]
+    lib.mopt_hess_update.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, DP, DP, DP]
+    lib.mopt_project_trrot_hess.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP]
+    lib.mopt_project_trrot_grad.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP]
+    lib.mopt_eigh.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, IP]
+    lib.mopt_bneb_force.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, C.c_int, C.c_int, DP, DP]
+    lib.mopt_rsirfo_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),
+                                    DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
+    if hasattr(lib, "mopt_band_create"):
+        lib.mopt_band_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        lib.mopt_band_destroy.argtypes = [vp]
+        lib.mopt_band_set_shard.argtypes = [vp, C.c_int, C.c_int]
+        lib.mopt_band_set_hessian.argtypes = [vp, C.c_int, DP]
+        lib.mopt_band_get_hessian.argtypes = [vp, C.c_int, DP]
+        lib.mopt_band_get_state.argtypes = [vp, C.c_int, C.POINTER(_abi.RsirfoState)]
+        lib.mopt_band_configure.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.mopt_band_upload.argtypes = [vp, DP, DP, DP]
+        lib.mopt_band_step.argtypes = [vp, C.c_int]
+        lib.mopt_band_download.argtypes = [vp, DP, DP, DP]
+
+
+def lib():
+    """The loaded shared library; raises MoptError when it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise MoptError(
+                        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950).  multioptpy_amd has no CPU fallback.")
+                l = C.CDLL(LIB_PATH)
+                _proto(l)
+                if l.mopt_abi_version() != 1:
+                    raise MoptError("libmopt_hip.so ABI version mismatch")
+                _lib = l
+    return _lib
+
+
+def ctx(device=None):
+    """One context per device per process (LOCAL_RANK selects the device under torch.distributed.run)."""
+    if device is None:
+        device = int(os.environ.get("MOPT_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    with _lock:
+        c = _ctx.get(device)
+    if c is None:
+        l = lib()
+        h = C.c_void_p()
+        rc = l.mopt_ctx_create(device, C.byref(h))
+        if rc != 0 or not h:
+            raise MoptError(f"mopt_ctx_create(device={device}) failed with {rc}: no usable HIP device "
+                            "(multioptpy_amd needs an MI355X; there is no CPU fallback)")
+        with _lock:
+            _ctx[device] = h
+        c = h
+    return c
+
+
+def check(rc, c=None):
+    if rc != 0:
+        msg = lib().mopt_last_error(c).decode() if c else ""
+        if rc == -4:
+            raise ValueError(msg or "call sequence error")
+        raise MoptError(f"libmopt_hip error {rc}: {msg}")
+
+
+def f64(a):
+    """C-contiguous float64 view/copy."""
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ptr(a):
+    return a.ctypes.data_as(DP) if a is not None else None

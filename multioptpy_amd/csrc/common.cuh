@@ -1,0 +1,118 @@
+// Shared device helpers for the gfx950 kernels (wave64 reductions, launch bookkeeping).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mopt_hip.h"
+
+namespace mopt {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ int wave_min_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { int t = __shfl_xor(v, o, WAVE); v = t < v ? t : v; }
+    return v;
+}
+
+// Block-wide sum of K values per thread; blockDim.x must be a multiple of 64 and <= 1024.
+// red must point to K * 16 doubles of LDS.  Result is returned to every thread.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();                       // protect red[] from a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) red[k * 16 + wid] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int w = 0; w < nw; ++w) a += red[k * 16 + w];
+        v[k] = a;
+    }
+}
+
+__device__ __forceinline__ double block_sum1(double x, double *red) {
+    double v[1] = {x};
+    block_sum<1>(v, red);
+    return v[0];
+}
+
+// Lane-strided reducer over a single wave: the `R` concept of logic.h.
+struct WaveRed {
+    template <class F> __device__ double sum(int m, F f) const {
+        double a = 0.0;
+        for (int i = threadIdx.x & 63; i < m; i += WAVE) a += f(i);
+        return wave_sum(a);
+    }
+    template <class P> __device__ int min_index(int m, P p) const {
+        int best = m;
+        for (int i = threadIdx.x & 63; i < m; i += WAVE) if (p(i)) { best = i; break; }
+        return wave_min_int(best);
+    }
+    template <class F> __device__ void for_each(int m, F f) const {
+        for (int i = threadIdx.x & 63; i < m; i += WAVE) f(i);
+    }
+    __device__ void sync() const { __syncthreads(); }
+};
+
+}  // namespace mopt
+
+// ---- host side --------------------------------------------------------------------------
+struct mopt_timer { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0.0; int64_t launches = 0; };
+
+struct mopt_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    std::map<std::string, mopt_timer> timers;
+    int lds_limit = 65536;
+    int num_cu = 256;
+    // generic scratch arena (grow-only)
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+};
+
+#define MOPT_HIP_TRY(ctx, call)                                                        \
+    do {                                                                               \
+        hipError_t e__ = (call);                                                       \
+        if (e__ != hipSuccess) {                                                       \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);           \
+            return MOPT_E_DEVICE;                                                      \
+        }                                                                              \
+    } while (0)
+
+// Scoped timing of a kernel family on the ctx stream (HIP events; only when ctx->timing).
+struct mopt_scope {
+    mopt_ctx *c; const char *name; hipEvent_t a = nullptr, b = nullptr; int n;
+    mopt_scope(mopt_ctx *ctx, const char *nm, int nlaunch = 1) : c(ctx), name(nm), n(nlaunch) {
+        if (c->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    }
+    ~mopt_scope() {
+        if (c->timing) {
+            hipEventRecord(b, c->stream);
+            auto &t = c->timers[name];
+            t.ev.emplace_back(a, b);
+            t.launches += n;
+        }
+    }
+};

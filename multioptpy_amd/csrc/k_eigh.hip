@@ -1,0 +1,270 @@
+// Batched symmetric eigensolver for gfx950: shifted one-sided (Hestenes) block Jacobi.
+//
+// numpy.linalg.eigh stands behind rsirfo.py:606,626,652 in the reference.  Here:
+//   A' = A + sigma I with sigma = 1.0625 ||A||_inf  (positive definite, kappa <= 33)
+//   G = A' V, V = I; plane rotations orthogonalise the columns of G (same rotations applied to V).
+//   At convergence G^T G is diagonal, so V diagonalises A'^2 and, A' being positive definite, A' itself
+//   (off-diagonal of V^T A' V <= tol * min eigenvalue).  lambda_i = v_i . g_i - sigma.
+// Storage is vector-major: row i of Gt / Vt is the i-th column vector (contiguous, coalesced).
+// One workgroup owns a pair of column blocks (2*bw vectors of G and of V) in LDS -- 150 KB of the CU's
+// 160 KB -- and sweeps the pairs inside it with one wave per rotation; a round-robin tournament over
+// the nb blocks gives nb-1 launches per sweep, each with (nb/2) x batch independent workgroups.
+#include "common.cuh"
+#include "pipeline.h"
+
+namespace mopt {
+
+
+
+// sigma[b] = 1.0625 * max_i sum_j |A_ij|  (+1 when the matrix is exactly zero)
+__global__ void __launch_bounds__(256) k_jac_sigma(int n, const double *__restrict__ A, double *__restrict__ sigma) {
+    __shared__ double red[16];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const double *Ab = A + (size_t)b * n * n;
+    double mx = 0.0;
+    for (int r = wid; r < n; r += 4) {
+        double s = 0.0;
+        for (int j = lane; j < n; j += WAVE) s += fabs(Ab[(size_t)r * n + j]);
+        s = wave_sum(s);
+        mx = fmax(mx, s);
+    }
+    if (lane == 0) red[wid] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+        sigma[b] = (m > 0.0 && isfinite(m)) ? 1.0625 * m : 1.0;
+    }
+}
+
+// Gt = A + sigma I, Vt = I   (or, warm start: Gt = A' * Vt_prev^T rows -- see k_jac_warm)
+__global__ void k_jac_init(int n, const double *__restrict__ A, const double *__restrict__ sigma,
+                           double *__restrict__ Gt, double *__restrict__ Vt, int *__restrict__ rotcount) {
+    const int b = blockIdx.y;
+    const size_t off = (size_t)b * n * n;
+    const double sg = sigma[b];
+    const size_t tot = (size_t)n * n;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / n), j = (int)(e % n);
+        const double d = (i == j) ? 1.0 : 0.0;
+        Gt[off + e] = A[off + e] + sg * d;     // A symmetric: row i == column i
+        Vt[off + e] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x <= JAC_MAX_SWEEPS) rotcount[b * (JAC_MAX_SWEEPS + 1) + threadIdx.x] = 0;
+}
+
+// One outer tournament step.  grid = (nb/2, batch); block = 64 * bw threads; dynamic LDS = 2 * (2 bw) * n doubles.
+// sweep >= 1: returns at once when the previous sweep applied no rotation to this matrix.
+__global__ void k_jac_step(int n, int bw, int nb, int tstep, int sweep, double tol, double *__restrict__ Gt_,
+                           double *__restrict__ Vt_, int *__restrict__ rotcount) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.y;
+    int *rc = rotcount + b * (JAC_MAX_SWEEPS + 1);
+    if (sweep > 0 && rc[sweep - 1] == 0) return;
+    const int m = 2 * bw;
+    double *sG = sm;                      // [m][n]
+    double *sV = sm + (size_t)m * n;      // [m][n]
+    double *Gt = Gt_ + (size_t)b * n * n;
+    double *Vt = Vt_ + (size_t)b * n * n;
+    // block pair of this workgroup (round robin over nb blocks, nb even)
+    const int k = blockIdx.x;
+    int P, Q;
+    if (k == 0) { P = nb - 1; Q = tstep; }
+    else { P = (tstep + k) % (nb - 1); Q = (tstep - k + (nb - 1)) % (nb - 1); }
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    // load: wave w loads local slots w and w + bw
+    for (int half = 0; half < 2; ++half) {
+        const int slot = wid + half * bw;
+        const int gi = (half == 0 ? P : Q) * bw + wid;
+        if (gi < n) {
+            for (int j = lane; j < n; j += WAVE) {
+                sG[(size_t)slot * n + j] = Gt[(size_t)gi * n + j];
+                sV[(size_t)slot * n + j] = Vt[(size_t)gi * n + j];
+            }
+        }
+    }
+    __syncthreads();
+    int nrot = 0;
+    const bool full = (tstep == 0);       // intra-block pairs once per sweep, at the first tournament step
+    const int nsteps = full ? (m - 1) : bw;
+    for (int t = 0; t < nsteps; ++t) {
+        int p, q;
+        if (full) {
+            if (wid == 0) { p = m - 1; q = t; }
+            else { p = (t + wid) % (m - 1); q = (t - wid + (m - 1)) % (m - 1); }
+        } else {
+            p = wid; q = bw + (wid + t) % bw;
+        }
+        const int gp = (p < bw ? P * bw + p : Q * bw + (p - bw));
+        const int gq = (q < bw ? P * bw + q : Q * bw + (q - bw));
+        if (gp < n && gq < n) {
+            double *a = sG + (size_t)p * n, *c = sG + (size_t)q * n;
+            double aa = 0.0, cc = 0.0, ac = 0.0;
+            for (int j = lane; j < n; j += WAVE) {
+                const double x = a[j], y = c[j];
+                aa += x * x; cc += y * y; ac += x * y;
+            }
+            aa = wave_sum(aa); cc = wave_sum(cc); ac = wave_sum(ac);
+            if (fabs(ac) > tol * sqrt(aa * cc)) {
+                // de Rijk / Hestenes rotation annihilating g_p . g_q
+                const double zeta = (cc - aa) / (2.0 * ac);
+                const double tt = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + tt * tt);
+                const double sn = cs * tt;
+                double *va = sV + (size_t)p * n, *vc = sV + (size_t)q * n;
+                for (int j = lane; j < n; j += WAVE) {
+                    const double x = a[j], y = c[j];
+                    a[j] = cs * x - sn * y;
+                    c[j] = sn * x + cs * y;
+                    const double vx = va[j], vy = vc[j];
+                    va[j] = cs * vx - sn * vy;
+                    vc[j] = sn * vx + cs * vy;
+                }
+                ++nrot;
+            }
+        }
+        __syncthreads();
+    }
+    for (int half = 0; half < 2; ++half) {
+        const int slot = wid + half * bw;
+        const int gi = (half == 0 ? P : Q) * bw + wid;
+        if (gi < n) {
+            for (int j = lane; j < n; j += WAVE) {
+                Gt[(size_t)gi * n + j] = sG[(size_t)slot * n + j];
+                Vt[(size_t)gi * n + j] = sV[(size_t)slot * n + j];
+            }
+        }
+    }
+    if (lane == 0 && nrot) atomicAdd(&rc[sweep], nrot);
+}
+
+// lambda_i = v_i . g_i - sigma, ascending sort (bitonic, LDS), perm[k] = vector index of the k-th eigenvalue.
+// dynamic LDS: npow2 * (8 + 4) bytes.
+__global__ void __launch_bounds__(256) k_jac_finalize(int n, int npow2, const double *__restrict__ Gt_,
+                                                      const double *__restrict__ Vt_, const double *__restrict__ sigma,
+                                                      const int *__restrict__ rotcount, double *__restrict__ W,
+                                                      int *__restrict__ perm, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *key = sm;
+    int *idx = (int *)(sm + npow2);
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const double *Gt = Gt_ + (size_t)b * n * n, *Vt = Vt_ + (size_t)b * n * n;
+    const double sg = sigma[b];
+    for (int i = wid; i < n; i += 4) {
+        double d = 0.0;
+        for (int j = lane; j < n; j += WAVE) d += Vt[(size_t)i * n + j] * Gt[(size_t)i * n + j];
+        d = wave_sum(d);
+        if (lane == 0) { key[i] = d - sg; idx[i] = i; }
+    }
+    for (int i = n + threadIdx.x; i < npow2; i += blockDim.x) { key[i] = INFINITY; idx[i] = -1; }
+    __syncthreads();
+    // NaN keys: treat as +inf for ordering but remember
+    int bad = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) if (!isfinite(key[i])) bad = 1;
+    bad = __syncthreads_or(bad);
+    for (int kk = 2; kk <= npow2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = ((i & kk) == 0);
+                    const double ki = key[i], kl = key[l];
+                    const bool gt = (ki > kl) || (ki == kl && idx[i] > idx[l]) || (ki != ki && kl == kl);
+                    if (gt == up) {
+                        key[i] = kl; key[l] = ki;
+                        const int t = idx[i]; idx[i] = idx[l]; idx[l] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        W[(size_t)b * n + i] = key[i];
+        perm[(size_t)b * n + i] = idx[i];
+    }
+    if (threadIdx.x == 0) {
+        const int *rc = rotcount + b * (JAC_MAX_SWEEPS + 1);
+        int s = 0;
+        while (s < JAC_MAX_SWEEPS && rc[s] != 0) ++s;
+        info[2 * b] = s + 1;          // sweeps executed (the last one verified convergence)
+        info[2 * b + 1] = bad | ((s >= JAC_MAX_SWEEPS) ? 2 : 0);
+    }
+}
+
+// V[b][j][k] = Vt[b][perm[k]][j]  (eigenvectors in columns, sorted): only for the mopt_eigh entry point
+__global__ void __launch_bounds__(256) k_jac_gather(int n, const double *__restrict__ Vt_, const int *__restrict__ perm,
+                                                    double *__restrict__ V_) {
+    __shared__ double tile[32][33];
+    const int T = (n + 31) / 32;
+    const int bk = blockIdx.x / T, bj = blockIdx.x % T, b = blockIdx.y;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const double *Vt = Vt_ + (size_t)b * n * n;
+    double *V = V_ + (size_t)b * n * n;
+    for (int kk = 0; kk < 4; ++kk) {
+        int r = ty + 8 * kk, k = bk * 32 + r, j = bj * 32 + tx;
+        tile[r][tx] = (k < n && j < n) ? Vt[(size_t)perm[(size_t)b * n + k] * n + j] : 0.0;
+    }
+    __syncthreads();
+    for (int kk = 0; kk < 4; ++kk) {
+        int r = ty + 8 * kk, j = bj * 32 + r, k = bk * 32 + tx;
+        if (j < n && k < n) V[(size_t)j * n + k] = tile[tx][r];
+    }
+}
+
+}  // namespace mopt
+
+static int g_jac_lds_attr_done = 0;
+
+int mopt_jacobi_block_width(const mopt_ctx *ctx, int n) {
+    // largest power of two bw <= 16 with 2*(2bw)*n*8 bytes within the LDS limit (minus 1 KB slack)
+    int bw = 16;
+    while (bw > 1 && (size_t)32 * bw * n > (size_t)ctx->lds_limit - 1024) bw >>= 1;
+    if ((size_t)32 * bw * n > (size_t)ctx->lds_limit - 1024) return 0;
+    return bw;
+}
+
+int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
+                     int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps) {
+    using namespace mopt;
+    const int bw = mopt_jacobi_block_width(ctx, n);
+    if (bw == 0) { ctx->err = "mopt_eigh: n too large for the LDS-resident Jacobi panels"; return MOPT_E_ARG; }
+    int nb = (n + bw - 1) / bw;
+    if (nb & 1) ++nb;
+    if (nb < 2) nb = 2;
+    const size_t lds = (size_t)2 * (2 * bw) * n * sizeof(double);
+    if (!g_jac_lds_attr_done) {
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_jac_step, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+        g_jac_lds_attr_done = 1;
+    }
+    if (max_sweeps > JAC_MAX_SWEEPS) max_sweeps = JAC_MAX_SWEEPS;
+    const double tol = fmax(1e-14, 2.0 * sqrt((double)n) * 2.220446049250313e-16);
+    {
+        mopt_scope sc(ctx, "eigh_init", 2);
+        hipLaunchKernelGGL(k_jac_sigma, dim3(batch), dim3(256), 0, ctx->stream, n, d_A, d_sigma);
+        hipLaunchKernelGGL(k_jac_init, dim3(64, batch), dim3(256), 0, ctx->stream, n, d_A, d_sigma, d_Gt, d_Vt, d_rotcount);
+    }
+    {
+        mopt_scope sc(ctx, "eigh_jacobi", max_sweeps * (nb - 1));
+        for (int sweep = 0; sweep < max_sweeps; ++sweep)
+            for (int t = 0; t < nb - 1; ++t)
+                hipLaunchKernelGGL(k_jac_step, dim3(nb / 2, batch), dim3(64 * bw), lds, ctx->stream, n, bw, nb, t, sweep, tol,
+                                   d_Gt, d_Vt, d_rotcount);
+    }
+    {
+        mopt_scope sc(ctx, "eigh_final", 1);
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        hipLaunchKernelGGL(k_jac_finalize, dim3(batch), dim3(256), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_Gt, d_Vt,
+                           d_sigma, d_rotcount, d_W, d_perm, d_info);
+    }
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const int *d_perm, double *d_V) {
+    using namespace mopt;
+    const int T = (n + 31) / 32;
+    hipLaunchKernelGGL(k_jac_gather, dim3(T * T, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_perm, d_V);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}

@@ -1,0 +1,230 @@
+// C ABI of libmopt_hip.so (see include/mopt_hip.h): context, workspaces and the host-pointer entry points.
+#include <cstring>
+#include <new>
+
+#include "common.cuh"
+#include "logic.h"
+#include "pipeline.h"
+
+using namespace mopt;
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+extern "C" int mopt_abi_version(void) { return MOPT_ABI_VERSION; }
+
+extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
+    if (!out) return MOPT_E_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return MOPT_E_DEVICE;
+    mopt_ctx *c = new (std::nothrow) mopt_ctx();
+    if (!c) return MOPT_E_NOMEM;
+    c->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete c; return MOPT_E_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MOPT_E_DEVICE; }
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) c->lds_limit = v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cu = v;
+    *out = c;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
+    if (!ctx) return MOPT_E_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->timers) for (auto &e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    if (ctx->arena) hipFree(ctx->arena);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MOPT_OK;
+}
+
+extern "C" const char *mopt_last_error(const mopt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int mopt_ctx_sync(mopt_ctx *ctx) {
+    if (!ctx) return MOPT_E_ARG;
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_ctx_timing(mopt_ctx *ctx, int enable) {
+    if (!ctx) return MOPT_E_ARG;
+    hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->timers) for (auto &e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+    ctx->timers.clear();
+    ctx->timing = enable != 0;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_ctx_timing_read(mopt_ctx *ctx, const char *family, double *ms, int64_t *launches) {
+    if (!ctx || !family) return MOPT_E_ARG;
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    auto it = ctx->timers.find(family);
+    double tot = 0.0; int64_t nl = 0;
+    if (it != ctx->timers.end()) {
+        for (auto &e : it->second.ev) { float t = 0.f; if (hipEventElapsedTime(&t, e.first, e.second) == hipSuccess) tot += t; }
+        nl = it->second.launches;
+    }
+    if (ms) *ms = tot;
+    if (launches) *launches = nl;
+    return MOPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// small RAII device buffer for the host-pointer entry points
+// ------------------------------------------------------------------------------------------
+namespace {
+struct DBuf {
+    void *p = nullptr;
+    ~DBuf() { if (p) hipFree(p); }
+    int alloc(mopt_ctx *ctx, size_t bytes) {
+        if (bytes == 0) bytes = 8;
+        if (hipMalloc(&p, bytes) != hipSuccess) { ctx->err = "hipMalloc failed"; p = nullptr; return MOPT_E_NOMEM; }
+        return MOPT_OK;
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+#define TRY(x) do { int rc__ = (x); if (rc__ != MOPT_OK) return rc__; } while (0)
+#define H2D(ctx, dst, src, bytes) MOPT_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (ctx)->stream))
+#define D2H(ctx, dst, src, bytes) MOPT_HIP_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (ctx)->stream))
+}  // namespace
+
+static bool bad_dims(mopt_ctx *ctx, int n, int batch) {
+    if (!ctx) return true;
+    if (n < 3 || n % 3 != 0 || batch < 1 || n > MOPT_MAX_N) { ctx->err = "bad dimensions (need n = 3N, 3 <= n <= MOPT_MAX_N, batch >= 1)"; return true; }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------
+// building blocks
+// ------------------------------------------------------------------------------------------
+extern "C" int mopt_hess_update(mopt_ctx *ctx, int rule, int n, int batch, const double *H, const double *s, const double *y,
+                                double *H_inplace, double *H_sym, double *info) {
+    if (bad_dims(ctx, n, batch) || !H || !s || !y || !H_sym || rule < 0 || rule >= MOPT_RULE_COUNT) return MOPT_E_ARG;
+    hipSetDevice(ctx->device);
+    const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
+    DBuf dH, dHi, dHs, ds, dy, du, dHy, dyd, dA, dcoef, dinfo, drules;
+    TRY(dH.alloc(ctx, nn)); TRY(dHs.alloc(ctx, nn)); if (H_inplace) TRY(dHi.alloc(ctx, nn));
+    TRY(ds.alloc(ctx, nv)); TRY(dy.alloc(ctx, nv)); TRY(du.alloc(ctx, nv)); TRY(dHy.alloc(ctx, nv)); TRY(dyd.alloc(ctx, nv)); TRY(dA.alloc(ctx, nv));
+    TRY(dcoef.alloc(ctx, batch * sizeof(UpdateCoef))); TRY(dinfo.alloc(ctx, (size_t)batch * 8 * sizeof(double)));
+    TRY(drules.alloc(ctx, batch * sizeof(int)));
+    std::vector<int> rules(batch, rule);
+    H2D(ctx, dH.p, H, nn); H2D(ctx, ds.p, s, nv); H2D(ctx, dy.p, y, nv); H2D(ctx, drules.p, rules.data(), batch * sizeof(int));
+    TRY(mopt_launch_hess_update(ctx, n, batch, drules.as<int>(), nullptr, rule == MOPT_RULE_FLOWCHART, nullptr, nullptr, nullptr, nullptr,
+                                ds.as<double>(), dy.as<double>(), du.as<double>(), dHy.as<double>(), dyd.as<double>(), dA.as<double>(),
+                                dcoef.as<UpdateCoef>(), dinfo.as<double>(), dH.as<double>(), H_inplace ? dHi.as<double>() : nullptr,
+                                dHs.as<double>(), true));
+    D2H(ctx, H_sym, dHs.p, nn);
+    if (H_inplace) D2H(ctx, H_inplace, dHi.p, nn);
+    if (info) D2H(ctx, info, dinfo.p, (size_t)batch * 8 * sizeof(double));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_project_trrot_hess(mopt_ctx *ctx, int n, int batch, const double *H, const double *X, double *Hp) {
+    if (bad_dims(ctx, n, batch) || !H || !X || !Hp) return MOPT_E_ARG;
+    hipSetDevice(ctx->device);
+    const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
+    DBuf dH, dA, dX, dQ, dW;
+    TRY(dH.alloc(ctx, nn)); TRY(dA.alloc(ctx, nn)); TRY(dX.alloc(ctx, nv)); TRY(dQ.alloc(ctx, 6 * nv)); TRY(dW.alloc(ctx, 6 * nv));
+    H2D(ctx, dH.p, H, nn); H2D(ctx, dX.p, X, nv);
+    TRY(mopt_launch_project_hess(ctx, n, batch, dH.as<double>(), nullptr, dX.as<double>(), dQ.as<double>(), dW.as<double>(), dA.as<double>()));
+    D2H(ctx, Hp, dA.p, nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_project_trrot_grad(mopt_ctx *ctx, int n, int batch, const double *g, const double *X, double *gp) {
+    if (bad_dims(ctx, n, batch) || !g || !X || !gp) return MOPT_E_ARG;
+    hipSetDevice(ctx->device);
+    const size_t nv = (size_t)batch * n * sizeof(double);
+    DBuf dg, dX, dgp;
+    TRY(dg.alloc(ctx, nv)); TRY(dX.alloc(ctx, nv)); TRY(dgp.alloc(ctx, nv));
+    H2D(ctx, dg.p, g, nv); H2D(ctx, dX.p, X, nv);
+    TRY(mopt_launch_project_grad(ctx, n, batch, dg.as<double>(), dX.as<double>(), dgp.as<double>()));
+    D2H(ctx, gp, dgp.p, nv);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, double *W, double *V, int *sweeps_out) {
+    if (!ctx) return MOPT_E_ARG;
+    if (n < 1 || batch < 1 || n > MOPT_MAX_N || !A || !W || !V) { ctx->err = "mopt_eigh: bad arguments"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
+    DBuf dA, dG, dVt, dV, dsig, drot, dW, dperm, dinfo;
+    TRY(dA.alloc(ctx, nn)); TRY(dG.alloc(ctx, nn)); TRY(dVt.alloc(ctx, nn)); TRY(dV.alloc(ctx, nn));
+    TRY(dsig.alloc(ctx, batch * sizeof(double))); TRY(drot.alloc(ctx, (size_t)batch * (JAC_MAX_SWEEPS + 1) * sizeof(int)));
+    TRY(dW.alloc(ctx, nv)); TRY(dperm.alloc(ctx, (size_t)batch * n * sizeof(int))); TRY(dinfo.alloc(ctx, (size_t)batch * 2 * sizeof(int)));
+    H2D(ctx, dA.p, A, nn);
+    TRY(mopt_launch_eigh(ctx, n, batch, dA.as<double>(), dsig.as<double>(), dG.as<double>(), dVt.as<double>(), drot.as<int>(),
+                         dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), MOPT_DEFAULT_SWEEPS));
+    TRY(mopt_launch_eig_gather(ctx, n, batch, dVt.as<double>(), dperm.as<int>(), dV.as<double>()));
+    D2H(ctx, W, dW.p, nv); D2H(ctx, V, dV.p, nn);
+    std::vector<int> info(2 * batch);
+    D2H(ctx, info.data(), dinfo.p, (size_t)batch * 2 * sizeof(int));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (sweeps_out) for (int b = 0; b < batch; ++b) sweeps_out[b] = info[2 * b];
+    return MOPT_OK;
+}
+
+extern "C" int mopt_bneb_force(mopt_ctx *ctx, int I, int N, const double *X, const double *E, const double *G, int optimize_num,
+                               int apply_ci_neb, double *F, double *tau) {
+    if (!ctx) return MOPT_E_ARG;
+    if (I < 2 || N < 1 || !X || !E || !G || !F || !tau) { ctx->err = "mopt_bneb_force: bad arguments"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    const size_t nv = (size_t)I * N * 3 * sizeof(double);
+    DBuf dX, dE, dG, dF, dT;
+    TRY(dX.alloc(ctx, nv)); TRY(dE.alloc(ctx, I * sizeof(double))); TRY(dG.alloc(ctx, nv)); TRY(dF.alloc(ctx, nv)); TRY(dT.alloc(ctx, nv));
+    H2D(ctx, dX.p, X, nv); H2D(ctx, dE.p, E, I * sizeof(double)); H2D(ctx, dG.p, G, nv);
+    TRY(mopt_launch_bneb_force(ctx, I, N, 0, I, dX.as<double>(), dE.as<double>(), dG.as<double>(), optimize_num > apply_ci_neb ? 1 : 0,
+                               dF.as<double>(), dT.as<double>()));
+    D2H(ctx, F, dF.p, nv); D2H(ctx, tau, dT.p, nv);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// RSIRFO.run on host buffers
+// ------------------------------------------------------------------------------------------
+extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *params, mopt_rsirfo_state *state,
+                               const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
+                               const double *g, const double *pre_geom, const double *pre_g, const double *B_e, double *step,
+                               double *H_inplace, double *H_sym) {
+    if (bad_dims(ctx, n, batch)) return MOPT_E_ARG;
+    if (!params || !state || !geom || !B_g || !B_e || !step) { ctx->err = "mopt_rsirfo_run: null argument"; return MOPT_E_ARG; }
+    if (!hessian) { ctx->err = "Hessian matrix must be set before running optimization"; return MOPT_E_STATE; }
+    hipSetDevice(ctx->device);
+    RsirfoWork wk;
+    TRY(wk.alloc(ctx, n, batch, /*own_hessian=*/true, bias_hessian != nullptr, H_inplace != nullptr));
+    const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
+    H2D(ctx, wk.H, hessian, nn);
+    if (bias_hessian) H2D(ctx, wk.Bias, bias_hessian, nn);
+    H2D(ctx, wk.x, geom, nv); H2D(ctx, wk.bg, B_g, nv);
+    H2D(ctx, wk.g, g ? g : B_g, nv);
+    const bool have_prev = pre_geom && pre_g;
+    if (have_prev) { H2D(ctx, wk.px, pre_geom, nv); H2D(ctx, wk.pg, pre_g, nv); }
+    H2D(ctx, wk.be, B_e, batch * sizeof(double));
+    H2D(ctx, wk.params, params, batch * sizeof(mopt_rsirfo_params));
+    H2D(ctx, wk.states, state, batch * sizeof(mopt_rsirfo_state));
+    std::vector<int> rules(batch), upd(batch);
+    bool any_flow = false, any_upd = false;
+    for (int b = 0; b < batch; ++b) {
+        rules[b] = params[b].rule;
+        if (rules[b] < 0 || rules[b] >= MOPT_RULE_COUNT) { ctx->err = "unknown update rule"; return MOPT_E_ARG; }
+        upd[b] = (have_prev && state[b].has_prev) ? 1 : 0;       // rsirfo.py:308
+        any_flow |= (rules[b] == MOPT_RULE_FLOWCHART);
+        any_upd |= upd[b] != 0;
+    }
+    H2D(ctx, wk.rules, rules.data(), batch * sizeof(int));
+    H2D(ctx, wk.do_update, upd.data(), batch * sizeof(int));
+    TRY(mopt_rsirfo_pipeline(ctx, wk, n, batch, any_upd, any_flow, wk.Hinpl, wk.H /* symmetrised in place */));
+    D2H(ctx, step, wk.step, nv);
+    D2H(ctx, state, wk.states, batch * sizeof(mopt_rsirfo_state));
+    if (H_sym) D2H(ctx, H_sym, wk.H, nn);
+    if (H_inplace) D2H(ctx, H_inplace, any_upd ? wk.Hinpl : wk.H, nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}

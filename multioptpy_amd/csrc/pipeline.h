@@ -1,0 +1,55 @@
+// Internal (non-ABI) interfaces between the translation units of libmopt_hip.so.
+#pragma once
+#include "common.cuh"
+#include "logic.h"
+
+#define MOPT_MAX_N 1500            /* 3N; bounded by the LDS staging of the 6 TR/rot vectors (12 n doubles) */
+#define MOPT_DEFAULT_SWEEPS 16     /* Jacobi sweeps launched per solve; converged matrices skip the rest */
+
+namespace mopt {
+constexpr int JAC_MAX_SWEEPS = 30;
+}
+
+// Device workspace of one batched RSIRFO.run (all pointers are device pointers).
+struct RsirfoWork {
+    mopt_ctx *ctx = nullptr;
+    int n = 0, batch = 0;
+    void *block = nullptr;        // single allocation
+    bool owns_H = false;
+    double *H = nullptr, *Bias = nullptr, *Hinpl = nullptr;       // [B][n][n]
+    double *A = nullptr, *Gt = nullptr, *Vt = nullptr;            // [B][n][n]
+    double *x = nullptr, *bg = nullptr, *g = nullptr, *px = nullptr, *pg = nullptr;   // [B][n]
+    double *s = nullptr, *y = nullptr, *u = nullptr, *Hy = nullptr, *yd = nullptr, *Av = nullptr;
+    double *gp = nullptr, *Q = nullptr, *W6 = nullptr, *eigw = nullptr, *gt_all = nullptr, *coefout = nullptr, *step = nullptr;
+    double *be = nullptr, *sigma = nullptr, *info = nullptr;
+    int *perm = nullptr, *einfo = nullptr, *rotcount = nullptr, *rules = nullptr, *do_update = nullptr;
+    mopt::UpdateCoef *coef = nullptr;
+    mopt_rsirfo_params *params = nullptr;
+    mopt_rsirfo_state *states = nullptr;
+    int alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool with_bias, bool with_inplace);
+    ~RsirfoWork();
+};
+
+// update (optional) -> TR/rot projections -> eigh -> RS-I-RFO step.  Hsym may alias wk.H (in-place).
+int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
+                         double *d_Hinpl, double *d_Hsym);
+
+// launchers (defined next to their kernels)
+int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules, const int *d_do_update, bool any_flowchart,
+                            const double *d_x, const double *d_px, const double *d_g, const double *d_pg,
+                            double *d_s, double *d_y, double *d_u, double *d_Hy, double *d_yd, double *d_A,
+                            mopt::UpdateCoef *d_coef, double *d_info, const double *d_H, double *d_Hinpl, double *d_Hsym,
+                            bool have_sy);
+int mopt_launch_project_hess(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, const double *d_X,
+                             double *d_Q, double *d_W, double *d_A);
+int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp);
+int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
+int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
+                     int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps);
+int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const int *d_perm, double *d_V);
+int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
+                    const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,
+                    const double *d_Bg, const double *d_Be, const mopt::UpdateCoef *d_coef, double *d_gt_all,
+                    double *d_coefout, double *d_step);
+int mopt_launch_bneb_force(mopt_ctx *ctx, int I, int N, int first, int count, const double *d_X, const double *d_E,
+                           const double *d_G, int ci_active, double *d_F, double *d_tau);

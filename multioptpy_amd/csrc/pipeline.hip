@@ -1,0 +1,63 @@
+// Batched RSIRFO.run pipeline on device buffers (multioptpy/Optimizer/rsirfo.py:285-490).
+#include "pipeline.h"
+
+RsirfoWork::~RsirfoWork() {
+    if (block) hipFree(block);
+}
+
+int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool with_bias, bool with_inplace) {
+    ctx = c; n = n_; batch = batch_; owns_H = own_hessian;
+    const size_t nn = (size_t)batch * n * n, nv = (size_t)batch * n;
+    auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    size_t tot = 0;
+    const int nmat = 3 + (own_hessian ? 1 : 0) + (with_bias ? 1 : 0) + (with_inplace ? 1 : 0);
+    tot += nmat * al(nn * 8);
+    tot += 17 * al(nv * 8);            // vectors
+    tot += 2 * al(nv * 6 * 8);         // Q, W6
+    tot += al(nv * 4);                 // perm
+    tot += 3 * al((size_t)batch * 8) + al((size_t)batch * 8 * 8);
+    tot += al((size_t)batch * 2 * 4) + al((size_t)batch * (mopt::JAC_MAX_SWEEPS + 1) * 4) + 2 * al((size_t)batch * 4);
+    tot += al(batch * sizeof(mopt::UpdateCoef)) + al(batch * sizeof(mopt_rsirfo_params)) + al(batch * sizeof(mopt_rsirfo_state));
+    if (hipMalloc(&block, tot) != hipSuccess) { c->err = "hipMalloc failed (RSIRFO workspace)"; block = nullptr; return MOPT_E_NOMEM; }
+    char *p = (char *)block;
+    auto take = [&](size_t bytes) { void *r = p; p += al(bytes); return r; };
+    if (own_hessian) H = (double *)take(nn * 8);
+    if (with_bias) Bias = (double *)take(nn * 8);
+    if (with_inplace) Hinpl = (double *)take(nn * 8);
+    A = (double *)take(nn * 8); Gt = (double *)take(nn * 8); Vt = (double *)take(nn * 8);
+    double **vecs[17] = {&x, &bg, &g, &px, &pg, &s, &y, &u, &Hy, &yd, &Av, &gp, &eigw, &gt_all, &coefout, &step, nullptr};
+    for (int i = 0; i < 16; ++i) *vecs[i] = (double *)take(nv * 8);
+    take(nv * 8);
+    Q = (double *)take(nv * 6 * 8); W6 = (double *)take(nv * 6 * 8);
+    perm = (int *)take(nv * 4);
+    be = (double *)take((size_t)batch * 8); sigma = (double *)take((size_t)batch * 8); take((size_t)batch * 8);
+    info = (double *)take((size_t)batch * 8 * 8);
+    einfo = (int *)take((size_t)batch * 2 * 4);
+    rotcount = (int *)take((size_t)batch * (mopt::JAC_MAX_SWEEPS + 1) * 4);
+    rules = (int *)take((size_t)batch * 4); do_update = (int *)take((size_t)batch * 4);
+    coef = (mopt::UpdateCoef *)take(batch * sizeof(mopt::UpdateCoef));
+    params = (mopt_rsirfo_params *)take(batch * sizeof(mopt_rsirfo_params));
+    states = (mopt_rsirfo_state *)take(batch * sizeof(mopt_rsirfo_state));
+    return MOPT_OK;
+}
+
+int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
+                         double *d_Hinpl, double *d_Hsym) {
+    int rc;
+    const mopt::UpdateCoef *coef = nullptr;
+    if (any_update) {
+        rc = mopt_launch_hess_update(ctx, n, batch, wk.rules, wk.do_update, any_flowchart, wk.x, wk.px, wk.g, wk.pg, wk.s, wk.y,
+                                     wk.u, wk.Hy, wk.yd, wk.Av, wk.coef, wk.info, wk.H, d_Hinpl, d_Hsym, false);
+        if (rc != MOPT_OK) return rc;
+        coef = wk.coef;
+    }
+    rc = mopt_launch_project_grad(ctx, n, batch, wk.bg, wk.x, wk.gp);
+    if (rc != MOPT_OK) return rc;
+    rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A);
+    if (rc != MOPT_OK) return rc;
+    rc = mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS);
+    if (rc != MOPT_OK) return rc;
+    rc = mopt_launch_rfo(ctx, n, batch, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, wk.gp, wk.bg, wk.be, coef,
+                         wk.gt_all, wk.coefout, wk.step);
+    return rc;
+}

@@ -1,0 +1,74 @@
+"""Thin NumPy-facing wrappers over the building-block entry points of libmopt_hip.so."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import lib, ctx, check, f64, ptr, IP
+
+
+def hess_update(method, H, s, y, want_inplace=True):
+    """delta-H application for a batch: H (B,n,n) or (n,n); returns (H_inplace, H_sym, info)."""
+    H = f64(H)
+    single = H.ndim == 2
+    H3 = H.reshape((-1,) + H.shape[-2:])
+    B, n = H3.shape[0], H3.shape[1]
+    s = f64(s).reshape(B, n)
+    y = f64(y).reshape(B, n)
+    Hi = np.empty_like(H3) if want_inplace else None
+    Hs = np.empty_like(H3)
+    info = np.zeros((B, 8))
+    c = ctx()
+    check(lib().mopt_hess_update(c, _abi.rule_from_method(method), n, B, ptr(H3), ptr(s), ptr(y), ptr(Hi), ptr(Hs), ptr(info)), c)
+    if single:
+        return (Hi[0] if Hi is not None else None), Hs[0], info[0]
+    return Hi, Hs, info
+
+
+def project_hess(H, X):
+    H = f64(H)
+    H3 = H.reshape((-1,) + H.shape[-2:])
+    B, n = H3.shape[0], H3.shape[1]
+    X = f64(X).reshape(B, n)
+    out = np.empty_like(H3)
+    c = ctx()
+    check(lib().mopt_project_trrot_hess(c, n, B, ptr(H3), ptr(X), ptr(out)), c)
+    return out.reshape(H.shape)
+
+
+def project_grad(g, X):
+    g = f64(g)
+    n = g.shape[-1] if g.ndim > 1 else g.size
+    g2 = g.reshape(-1, n)
+    B = g2.shape[0]
+    X = f64(X).reshape(B, n)
+    out = np.empty_like(g2)
+    c = ctx()
+    check(lib().mopt_project_trrot_grad(c, n, B, ptr(g2), ptr(X), ptr(out)), c)
+    return out.reshape(g.shape)
+
+
+def eigh(A, return_sweeps=False):
+    A = f64(A)
+    A3 = A.reshape((-1,) + A.shape[-2:])
+    B, n = A3.shape[0], A3.shape[1]
+    W = np.empty((B, n))
+    V = np.empty_like(A3)
+    sw = np.zeros(B, dtype=np.int32)
+    c = ctx()
+    check(lib().mopt_eigh(c, n, B, ptr(A3), ptr(W), ptr(V), sw.ctypes.data_as(IP)), c)
+    if A.ndim == 2:
+        W, V = W[0], V[0]
+    return (W, V, sw) if return_sweeps else (W, V)
+
+
+def bneb_force(X, E, G, optimize_num=0, apply_ci_neb=99999):
+    X = f64(X)
+    I, N = X.shape[0], X.shape[1]
+    E = f64(E)
+    G = f64(G)
+    F = np.empty_like(X)
+    tau = np.empty_like(X)
+    c = ctx()
+    check(lib().mopt_bneb_force(c, I, N, ptr(X), ptr(E), ptr(G), int(optimize_num), int(apply_ci_neb), ptr(F), ptr(tau)), c)
+    return F, tau

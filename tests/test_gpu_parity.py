@@ -1,0 +1,175 @@
+"""GPU parity: the HIP path, called through the C ABI (ctypes), against the golden vectors captured from the
+reference and against the CPU oracle on identical seeded inputs.  Tolerances: step vectors / Hessians / forces
+1e-8 a.u. absolute as BASELINE.json's north_star states (most checks are far tighter)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from multioptpy_amd import ops as o
+    from multioptpy_amd._lib import ctx
+    ctx()
+    return o
+
+
+def test_hess_update_all_rules_vs_reference(ops):
+    z = np.load(os.path.join(G, "g1_updates.npz"))
+    ncase = sum(1 for k in z.files if k.endswith("_delta"))
+    applied = 0
+    for i in range(ncase):
+        tag = f"c{i:03d}"
+        n, indef, seed = z[tag + "_meta"]
+        kind = str(z[tag + "_kind"])
+        method = str(z[tag + "_method"])
+        H = cases.spd_matrix(int(n), seed=int(n) + int(indef), indefinite=bool(indef))
+        s, y = cases.sy_pair(H, seed=int(seed), kind=kind)
+        Hin, Hsym, info = ops.hess_update(method, H, s, y)
+        ref = z[tag + "_delta"]
+        if info[0] == 0:
+            # RSIRFO.update_hessian's own guards (rsirfo.py:1326-1335) skipped it: H must come back untouched
+            assert np.linalg.norm(s) < 1e-10 or np.linalg.norm(y) < 1e-10 or s @ y <= 0
+            assert np.array_equal(Hin, H) and np.array_equal(Hsym, H)
+            continue
+        applied += 1
+        scale = max(1.0, np.abs(ref).max())
+        assert np.abs((Hin - H) - ref).max() / scale < 1e-9, (tag, method, kind)
+        full = H + ref
+        assert np.abs(Hsym - 0.5 * (full + full.T)).max() / scale < 1e-9, (tag, method, kind)
+    assert applied > 300
+
+
+def test_hess_update_batched(ops):
+    rng = np.random.default_rng(0)
+    B, n = 5, 33
+    Hs = np.array([cases.spd_matrix(n, seed=k) for k in range(B)])
+    S = 0.01 * rng.normal(size=(B, n))
+    Y = np.einsum("bij,bj->bi", Hs, S) + 0.001 * rng.normal(size=(B, n))
+    from oracle import hessian_update as hu
+    Hin, Hsym, info = ops.hess_update("rsirfo_block_bofill", Hs, S, Y)
+    for b in range(B):
+        d = hu.delta_hessian("rsirfo_block_bofill", Hs[b], S[b], Y[b])
+        assert np.abs(Hin[b] - (Hs[b] + d)).max() < 1e-11
+
+
+def test_projections_vs_reference(ops):
+    z = np.load(os.path.join(G, "g5_projections.npz"))
+    for name in ("ar7", "ar22", "linear_z", "diatomic"):
+        x, H, g = z[name + "_x"], z[name + "_H"], z[name + "_g"]
+        Hp = ops.project_hess(H, x)
+        assert np.abs(Hp - z[name + "_Hp"]).max() < 1e-11, name
+        gp = ops.project_grad(g, x)
+        assert np.abs(gp - z[name + "_gp"]).max() < 1e-11, name
+
+
+@pytest.mark.parametrize("n", [3, 21, 66, 150, 300])
+def test_eigh_random(ops, n):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(n, n))
+    A = 0.5 * (A + A.T)
+    w, v, sw = ops.eigh(A, return_sweeps=True)
+    wr = np.linalg.eigvalsh(A)
+    nrm = np.abs(wr).max()
+    assert np.all(np.diff(w) >= 0)
+    assert np.abs(w - wr).max() < 5e-13 * nrm, (n, np.abs(w - wr).max())
+    assert np.abs(v.T @ v - np.eye(n)).max() < 1e-12
+    assert np.abs(A @ v - v * w).max() < 5e-12 * nrm
+    assert 1 <= sw[0] <= 16
+
+
+def test_eigh_degenerate_and_batched(ops):
+    # projected identity (n-6 fold degenerate 1, six zero modes), an LJ Hessian and a diagonal matrix in one batch
+    N = 22
+    n = 3 * N
+    x = cases.cluster(N)
+    from oracle import projection as pj
+    P1 = pj.project_hessian_trrot(np.eye(n), x)
+    H = pj.project_hessian_trrot(cases.lj(x, hessian=True)[2], x)
+    D = np.diag(np.linspace(-1, 2, n))
+    A = np.array([P1, H, D])
+    w, v, sw = ops.eigh(A, return_sweeps=True)
+    for b in range(3):
+        wr = np.linalg.eigvalsh(A[b])
+        scale = max(1.0, np.abs(wr).max())
+        assert np.abs(w[b] - wr).max() < 1e-13 * scale + 1e-15, (b, np.abs(w[b] - wr).max())
+        assert np.abs(v[b].T @ v[b] - np.eye(n)).max() < 1e-12
+        assert np.abs(A[b] @ v[b] - v[b] * w[b]).max() < 1e-12 * scale
+    assert np.sum(np.abs(w[0]) < 1e-10) == 6
+    assert sw[2] <= 2
+
+
+def test_bneb_force_vs_reference(ops):
+    z = np.load(os.path.join(G, "g6_neb_force.npz"))
+    for k in range(int(z["ncase"])):
+        tag = f"f{k:02d}"
+        X, E, Gr = z[tag + "_X"], z[tag + "_E"], z[tag + "_G"]
+        F, tau = ops.bneb_force(X, E, Gr, optimize_num=5, apply_ci_neb=(2 if int(z[tag + "_ci"]) else 99999))
+        assert np.abs(F - z[tag + "_F"]).max() < 1e-12, tag
+        assert np.abs(tau - z[tag + "_tau"]).max() < 1e-12, tag
+
+
+def _replay_gpu(z, tag):
+    from multioptpy_amd.Optimizer.rsirfo import RSIRFO
+    N, so, neb, nsteps, seed = [int(v) for v in z[tag + "_meta"]]
+    method = str(z[tag + "_method"])
+    n = 3 * N
+    h0 = str(z[tag + "_h0kind"])
+    x0 = cases.cluster(N, seed_offset=seed)
+    if h0 == "exact":
+        H = cases.lj(x0, hessian=True)[2]
+    elif h0 == "identity":
+        H = np.eye(n)
+    else:
+        H = cases.spd_matrix(n, seed=seed)
+    opt = RSIRFO(method=method, saddle_order=so, trust_radius_max=0.5 if so == 0 else 0.1, trust_radius_min=0.01)
+    if neb:
+        opt.switch_NEB_mode()
+    px = pg = pE = None
+    for k in range(nsteps):
+        x = z[f"{tag}_s{k}_x"]
+        g = z[f"{tag}_s{k}_g"]
+        E = float(z[f"{tag}_s{k}_E"])
+        opt.set_hessian(H)
+        opt.set_bias_hessian(np.zeros((n, n)))
+        if k == 0:
+            step = opt.run(x, g, [], [], E, 0.0, [], [], g, [])
+        else:
+            step = opt.run(x, g, pg, px, E, pE, [], [], g, pg)
+        yield k, opt, step, H
+        px, pg, pE = x, g, E
+
+
+def test_rsirfo_traces_vs_reference():
+    """G2: consecutive RSIRFO.run calls (36 traces incl. N = 100) reproduce the reference's step, trust radius,
+    predicted energy change and both Hessian objects (the caller-aliased array and self.hessian)."""
+    z = np.load(os.path.join(G, "g2_rsirfo.npz"))
+    worst = 0.0
+    for i in range(int(z["ncfg"])):
+        tag = f"t{i:02d}"
+        for k, opt, step, Hcaller in _replay_gpu(z, tag):
+            ref = z[f"{tag}_s{k}_step"]
+            assert step.shape == ref.shape
+            err = np.abs(step - ref).max()
+            worst = max(worst, err)
+            assert err < 1e-8, (tag, k, err)
+            assert abs(opt.trust_radius - float(z[f"{tag}_s{k}_tr"])) < 1e-12, (tag, k)
+            pr = float(z[f"{tag}_s{k}_pred"])
+            assert abs(opt.predicted_energy_changes[-1] - pr) < 1e-8 * max(1.0, abs(pr)), (tag, k)
+            if f"{tag}_s{k}_Hself" in z.files:
+                assert np.abs(opt.hessian - z[f"{tag}_s{k}_Hself"]).max() < 1e-8, (tag, k)
+                assert np.abs(Hcaller - z[f"{tag}_s{k}_Hcaller"]).max() < 1e-8, (tag, k)
+    print("worst step deviation from the reference:", worst)
+
+
+def test_rsirfo_requires_hessian():
+    from multioptpy_amd.Optimizer.rsirfo import RSIRFO
+    opt = RSIRFO(method="rsirfo_bfgs", saddle_order=0)
+    with pytest.raises(ValueError):
+        opt.run(np.zeros((9, 1)), np.zeros((9, 1)))
