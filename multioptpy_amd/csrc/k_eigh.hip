@@ -150,10 +150,15 @@ __global__ void __launch_bounds__(256) k_jac_finalize(int n, int npow2, const do
     const double *Gt = Gt_ + (size_t)b * n * n, *Vt = Vt_ + (size_t)b * n * n;
     const double sg = sigma[b];
     for (int i = wid; i < n; i += 4) {
-        double d = 0.0;
-        for (int j = lane; j < n; j += WAVE) d += Vt[(size_t)i * n + j] * Gt[(size_t)i * n + j];
+        double d = 0.0, vv = 0.0;
+        for (int j = lane; j < n; j += WAVE) {
+            const double v = Vt[(size_t)i * n + j];
+            d += v * Gt[(size_t)i * n + j];
+            vv += v * v;
+        }
         d = wave_sum(d);
-        if (lane == 0) { key[i] = d - sg; idx[i] = i; }
+        vv = wave_sum(vv);             // rotations keep |v_i| = 1 only to rounding: Rayleigh quotient, not v.g
+        if (lane == 0) { key[i] = d / vv - sg; idx[i] = i; }
     }
     for (int i = n + threadIdx.x; i < npow2; i += blockDim.x) { key[i] = INFINITY; idx[i] = -1; }
     __syncthreads();
