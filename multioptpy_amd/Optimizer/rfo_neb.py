@@ -1,0 +1,63 @@
+"""RFOOptimizer: drop-in for ``multioptpy.Optimizer.rfo_neb.RFOOptimizer`` (reference rfo_neb.py:86-208).
+
+``optimize(...)`` keeps the reference's positional argument list (neb.py:926-931) and returns the new geometry
+list in Angstrom.  The whole step -- BNEB force, Ayala curvature correction, one RSIRFO.run per image, step limit,
+TR_calc, FIRE and the blend -- runs in libmopt_hip.so on a device-resident band (``mopt_band_step``).
+
+Hessian persistence.  The reference loads ``tmp_hessian_{i}.npy`` before and saves it after every image step
+(rfo_neb.py:18-25,175) because other parts of nebmain write those files (exact Hessians from the calculator, model
+Hessians, bias Hessians).  With ``persist_hessians=True`` (default when ``config.NEB_FOLDER_DIRECTORY`` is set) this
+class does the same round trip so it can sit under the unmodified driver; with ``False`` the Hessians never leave HBM.
+"""
+import os
+
+import numpy as np
+
+from ..band import Band
+
+
+class RFOOptimizer:
+    def __init__(self, config, persist_hessians=None, device=None):
+        self.config = config
+        self.apply_ts_opt = True
+        self.ratio_of_rfo_step = getattr(config, "ratio_of_rfo_step", 0.5)
+        self.folder = getattr(config, "NEB_FOLDER_DIRECTORY", None)
+        self.persist = (self.folder is not None) if persist_hessians is None else bool(persist_hessians)
+        self.device = device
+        self.band = None
+        self.optimizer_instance_list = []     # kept for API compatibility (state lives on the device)
+
+    def set_apply_ts_opt(self, apply_ts_opt):
+        self.apply_ts_opt = apply_ts_opt
+
+    def _file(self, i):
+        return os.path.join(self.folder, f"tmp_hessian_{i}.npy")
+
+    def optimize(self, geometry_num_list, total_force_list, prev_geometry_num_list, prev_total_force_list, optimize_num,
+                 biased_energy_list, pre_biased_energy_list, pre_total_velocity, total_velocity, cos_list, pre_geom,
+                 STRING_FORCE_CALC):
+        X = np.asarray(geometry_num_list, dtype=np.float64)
+        G = np.asarray(total_force_list, dtype=np.float64)
+        E = np.asarray(biased_energy_list, dtype=np.float64)
+        I, N = X.shape[0], X.shape[1]
+        if self.band is None or optimize_num == 0 or (self.band.I, self.band.N) != (I, N):
+            if self.band is not None:
+                self.band.close()
+            ci = getattr(STRING_FORCE_CALC, "APPLY_CI_NEB", 99999)
+            self.band = Band(I, N, device=self.device, ratio_of_rfo_step=self.ratio_of_rfo_step,
+                             fix_init_edge=getattr(self.config, "fix_init_edge", False),
+                             fix_end_edge=getattr(self.config, "fix_end_edge", False),
+                             apply_ts_opt=self.apply_ts_opt, apply_ci_neb=ci)
+        if self.persist:
+            for i in range(I):
+                f = self._file(i)
+                self.band.set_hessian(i, np.load(f) if os.path.exists(f) else None)
+        self.band.upload(X, E, G)
+        self.band.step(optimize_num)
+        newX, F = self.band.download(want_force=True)
+        if hasattr(STRING_FORCE_CALC, "tau_list"):
+            pass        # tau stays on the device; calc_force of the mirror class refreshes tau_list when called
+        if self.persist:
+            for i in range(I):
+                np.save(self._file(i), self.band.get_hessian(i))
+        return newX

@@ -1,0 +1,73 @@
+"""Device-resident NEB band (``mopt_band_*`` of include/mopt_hip.h)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._lib import lib, ctx, check, f64, ptr
+
+
+class Band:
+    """I images of N atoms; this process owns images [first, first+count) (image sharding, one process per GPU)."""
+
+    def __init__(self, I, N, first=0, count=None, device=None, ratio_of_rfo_step=0.5, fix_init_edge=False,
+                 fix_end_edge=False, apply_ts_opt=True, apply_ci_neb=99999):
+        self.I, self.N, self.n = int(I), int(N), 3 * int(N)
+        self.first = int(first)
+        self.count = self.I - self.first if count is None else int(count)
+        self._ctx = ctx(device)
+        self._h = C.c_void_p()
+        check(lib().mopt_band_create(self._ctx, self.I, self.N, C.byref(self._h)), self._ctx)
+        if self.first != 0 or self.count != self.I:
+            check(lib().mopt_band_set_shard(self._h, self.first, self.count), self._ctx)
+        check(lib().mopt_band_configure(self._h, float(ratio_of_rfo_step), int(bool(fix_init_edge)), int(bool(fix_end_edge)),
+                                        int(bool(apply_ts_opt)), int(apply_ci_neb)), self._ctx)
+
+    def close(self):
+        if self._h:
+            lib().mopt_band_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_hessian(self, image, H):
+        Hc = None if H is None else f64(H)
+        check(lib().mopt_band_set_hessian(self._h, int(image), ptr(Hc)), self._ctx)
+
+    def get_hessian(self, image):
+        H = np.empty((self.n, self.n))
+        check(lib().mopt_band_get_hessian(self._h, int(image), ptr(H)), self._ctx)
+        return H
+
+    def get_state(self, image):
+        s = _abi.RsirfoState()
+        check(lib().mopt_band_get_state(self._h, int(image), C.byref(s)), self._ctx)
+        return s
+
+    def upload(self, X, E, G):
+        X = f64(X).reshape(self.I, self.n)
+        G = f64(G).reshape(self.I, self.n)
+        E = f64(E).reshape(self.I)
+        check(lib().mopt_band_upload(self._h, ptr(X), ptr(E), ptr(G)), self._ctx)
+
+    def step(self, optimize_num):
+        check(lib().mopt_band_step(self._h, int(optimize_num)), self._ctx)
+
+    def sync(self):
+        check(lib().mopt_ctx_sync(self._ctx), self._ctx)
+
+    def download(self, want_force=False, want_rfo=False):
+        newX = np.empty((self.count, self.N, 3))
+        F = np.empty((self.I, self.N, 3)) if want_force else None
+        R = np.empty((self.count, self.N, 3)) if want_rfo else None
+        check(lib().mopt_band_download(self._h, ptr(newX), ptr(F), ptr(R)), self._ctx)
+        out = [newX]
+        if want_force:
+            out.append(F)
+        if want_rfo:
+            out.append(R)
+        return out[0] if len(out) == 1 else tuple(out)

@@ -1,0 +1,454 @@
+// Device-resident NEB band: RFOOptimizer.optimize (multioptpy/Optimizer/rfo_neb.py:104-208) with the per-image
+// Hessians and RSIRFO state kept in HBM between steps (the reference round-trips tmp_hessian_{i}.npy, :18-25,175).
+//   k_gamma     calculate_gamma (pathopt_bneb_force.py:161-222): quintic fit through (E, g.t) of the triplet
+//   k_rank1     H += gamma t t^T (rfo_neb.py:72)
+//   k_neb_post  step limit (rfo_neb.py:76-83) -> TR_calc (trust_radius_neb.py:17-98) -> FIRE (fire_neb.py:38-92)
+//               -> blend and Bohr->Angstrom (rfo_neb.py:193-206)
+#include <cstring>
+#include <new>
+
+#include "pipeline.h"
+
+namespace mopt {
+
+constexpr double BOHR2ANG = 0.52917721067;     // neb.py:201
+
+// 6x6 solve by LU with partial pivoting (numpy.linalg.solve = dgesv); returns false on an exactly zero pivot.
+__device__ inline bool solve6(double A[6][6], double b[6]) {
+    for (int k = 0; k < 6; ++k) {
+        int p = k;
+        double mx = fabs(A[k][k]);
+        for (int r = k + 1; r < 6; ++r) if (fabs(A[r][k]) > mx) { mx = fabs(A[r][k]); p = r; }
+        if (A[p][k] == 0.0) return false;
+        if (p != k) {
+            for (int c = 0; c < 6; ++c) { double t = A[k][c]; A[k][c] = A[p][c]; A[p][c] = t; }
+            double t = b[k]; b[k] = b[p]; b[p] = t;
+        }
+        for (int r = k + 1; r < 6; ++r) {
+            const double f = A[r][k] / A[k][k];
+            for (int c = k; c < 6; ++c) A[r][c] -= f * A[k][c];
+            b[r] -= f * b[k];
+        }
+    }
+    for (int k = 5; k >= 0; --k) {
+        double s = b[k];
+        for (int c = k + 1; c < 6; ++c) s -= A[k][c] * b[c];
+        b[k] = s / A[k][k];
+    }
+    return true;
+}
+
+// grid = owned images; gamma[local] (0 for end images)
+__global__ void __launch_bounds__(256) k_gamma(int I, int n, int first, const double *__restrict__ X, const double *__restrict__ E,
+                                               const double *__restrict__ G, const double *__restrict__ tau,
+                                               double *__restrict__ gamma) {
+    __shared__ double red[5 * 16];
+    const int loc = blockIdx.x, i = first + loc;
+    if (i == 0 || i == I - 1) { if (threadIdx.x == 0) gamma[loc] = 0.0; return; }
+    const double *xm = X + (size_t)(i - 1) * n, *x0 = X + (size_t)i * n, *xp = X + (size_t)(i + 1) * n;
+    const double *gm = G + (size_t)(i - 1) * n, *g0 = G + (size_t)i * n, *gp = G + (size_t)(i + 1) * n;
+    const double *t = tau + (size_t)i * n;
+    double v[5] = {0, 0, 0, 0, 0};
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const double dm = x0[k] - xm[k], dp = xp[k] - x0[k];
+        v[0] += dm * dm; v[1] += dp * dp; v[2] += gm[k] * dm; v[3] += g0[k] * t[k]; v[4] += gp[k] * dp;
+    }
+    block_sum<5>(v, red);
+    if (threadIdx.x == 0) {
+        const double dprev = sqrt(v[0]), dnext = sqrt(v[1]);
+        double gam = 0.0;
+        if (!(dprev < 1e-6 || dnext < 1e-6)) {
+            const double s[3] = {-dprev, 0.0, dnext};
+            double A[6][6], b[6];
+            for (int r = 0; r < 3; ++r) {
+                double pw = 1.0;
+                for (int c = 0; c < 6; ++c) { A[r][c] = pw; pw *= s[r]; }
+                A[3 + r][0] = 0.0;
+                pw = 1.0;
+                for (int c = 1; c < 6; ++c) { A[3 + r][c] = c * pw; pw *= s[r]; }
+            }
+            b[0] = E[i - 1]; b[1] = E[i]; b[2] = E[i + 1];
+            b[3] = v[2] / dprev; b[4] = v[3]; b[5] = v[4] / dnext;
+            if (solve6(A, b)) gam = 2.0 * b[2];
+        }
+        gamma[loc] = gam;
+    }
+}
+
+// H[loc] += gamma[loc] * t t^T      grid (ceil(n/8), owned), block 256: 8 rows per block, 32 lanes per row
+__global__ void __launch_bounds__(256) k_rank1(int n, int first, const double *__restrict__ gamma, const double *__restrict__ tau,
+                                               double *__restrict__ H) {
+    const int loc = blockIdx.y;
+    const double gam = gamma[loc];
+    if (gam == 0.0) return;
+    const double *t = tau + (size_t)(first + loc) * n;
+    const int r = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (r >= n) return;
+    const double tr = gam * t[r];
+    double *row = H + ((size_t)loc * n + r) * n;
+    for (int c = threadIdx.x & 31; c < n; c += 32) row[c] += tr * t[c];
+}
+
+struct TrIn { double r1, r2, c1, c2; };
+
+// TR_calc for one image given delta (trust_radius_neb.py:17-98).  Returns the scale applied to delta (0 = frozen).
+__device__ inline double tr_scale_edge(double nrm, bool fixed) {
+    if (fixed) return 0.0;
+    if (nrm < 1e-15) return 0.0;
+    return fmin(0.5, nrm) / nrm;
+}
+__device__ inline double tr_scale_interior(double dn, double r1, double r2, double c1, double c2, double fc) {
+    if (fc >= 0.0) {
+        if ((c1 > 0 && c2 < 0) || (c1 < 0 && c2 > 0)) {
+            if (dn > r1 && c1 > 0) return r1 / dn;
+            if (dn > r2 && c2 > 0) return r2 / dn;
+            return 1.0;
+        } else if (c1 < 0 && c2 < 0) {
+            return 1.0;
+        } else {
+            if (dn > r1) return r1 / dn;
+            if (dn > r2) return r2 / dn;
+            return 1.0;
+        }
+    }
+    return 0.0;
+}
+
+// grid = owned images, block 128, dynamic LDS: 2 * n doubles
+__global__ void __launch_bounds__(128) k_neb_post(int I, int N, int first, int optimize_num, int have_prev, double ratio, int fix_init,
+                                                  int fix_end, const double *__restrict__ X, const double *__restrict__ G,
+                                                  const double *__restrict__ F, const double *__restrict__ pF,
+                                                  const double *__restrict__ rfo_step, double *__restrict__ rfo_delta_out,
+                                                  double *__restrict__ newX) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[6 * 16];
+    const int n = 3 * N;
+    double *dl = sm;            // RFO delta (after the step limit)
+    double *fd = sm + n;        // FIRE total_delta
+    const int loc = blockIdx.x, i = first + loc;
+    const bool is_end = (i == 0 || i == I - 1);
+    const double *x0 = X + (size_t)i * n;
+    const double *g0 = G + (size_t)i * n;
+    const double *f0 = F + (size_t)i * n;
+    const double *rs = rfo_step + (size_t)loc * n;
+    // ---- FIRE global switch: sum over ALL images of pre_velocity . force (fire_neb.py:60-65)
+    double dotp = 0.0;
+    if (optimize_num != 0 && have_prev) {
+        double a = 0.0;
+        for (size_t k = threadIdx.x; k < (size_t)I * n; k += blockDim.x) a += pF[k] * F[k];
+        dotp = block_sum1(a, red);
+    }
+    const bool keep = (optimize_num > 0 && dotp > 0.0 && have_prev);
+    // a fresh FIREOptimizer every step (rfo_neb.py:187): dt = 0.5, a = 0.1, n_reset = 0 (never > N_accelerate)
+    const double fa = 0.1;
+    const double dt = keep ? 0.5 : 0.5 * 0.5;
+    // ---- step limit on the RFO move (rfo_neb.py:76-83)
+    double v6[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = threadIdx.x; k < n; k += blockDim.x) v6[0] += rs[k] * rs[k];
+    block_sum<6>(v6, red);
+    {
+        const double nrm = sqrt(v6[0]);
+        const double lim = is_end ? 0.2 : 0.1;
+        for (int k = threadIdx.x; k < n; k += blockDim.x) dl[k] = (nrm > 1e-8) ? rs[k] / nrm * fmin(lim, nrm) : rs[k];
+    }
+    // ---- FIRE velocity mixing per atom and total_delta
+    for (int a = threadIdx.x; a < N; a += blockDim.x) {
+        const double fx = f0[3 * a], fy = f0[3 * a + 1], fz = f0[3 * a + 2];
+        const double fn = sqrt(fx * fx + fy * fy + fz * fz);     // total_velocity == total_force here (neb.py:552,1159-1162)
+        double vx = fx, vy = fy, vz = fz;
+        if (fn > 1e-10) {
+            const double vn = fn;
+            vx = (1.0 - fa) * fx + fa * (vn / fn) * fx;
+            vy = (1.0 - fa) * fy + fa * (vn / fn) * fy;
+            vz = (1.0 - fa) * fz + fa * (vn / fn) * fz;
+        }
+        if (!keep) { vx *= 0.0; vy *= 0.0; vz *= 0.0; }
+        double tv[3] = {vx + dt * fx, vy + dt * fy, vz + dt * fz};
+        for (int c = 0; c < 3; ++c) {
+            const int k = 3 * a + c;
+            fd[k] = (optimize_num != 0 && have_prev) ? dt * (tv[c] + pF[(size_t)i * n + k]) : dt * tv[c];
+        }
+    }
+    __syncthreads();
+    double sc_rfo, sc_fire;
+    if (is_end) {
+        double w[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = threadIdx.x; k < n; k += blockDim.x) { w[0] += dl[k] * dl[k]; w[1] += fd[k] * fd[k]; }
+        block_sum<6>(w, red);
+        const bool fixed = (i == 0) ? (fix_init != 0) : (fix_end != 0);
+        sc_rfo = tr_scale_edge(sqrt(w[0]), fixed);
+        sc_fire = tr_scale_edge(sqrt(w[1]), fixed);
+    } else {
+        const double *xm = X + (size_t)(i - 1) * n, *xp = X + (size_t)(i + 1) * n;
+        // distances and the dots needed by both TR_calc calls
+        double w[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const double dm = xm[k] - x0[k], dp = xp[k] - x0[k];
+            w[0] += dm * dm; w[1] += dp * dp;
+            w[2] += dl[k] * dl[k]; w[3] += fd[k] * fd[k];
+            w[4] += g0[k] * g0[k]; w[5] += f0[k] * f0[k];
+        }
+        block_sum<6>(w, red);
+        const double d1 = sqrt(w[0]), d2 = sqrt(w[1]);
+        const double dnr = sqrt(w[2]), dnf = sqrt(w[3]), gnr = sqrt(w[4]), fnr = sqrt(w[5]);
+        double u[6] = {0, 0, 0, 0, 0, 0};
+        for (int k = threadIdx.x; k < n; k += blockDim.x) {
+            const double v1 = (xm[k] - x0[k]) / (d1 + 1e-15), v2 = (xp[k] - x0[k]) / (d2 + 1e-15);
+            const double ndr = dl[k] / dnr, ndf = fd[k] / dnf;
+            u[0] += v1 * ndr; u[1] += v2 * ndr; u[2] += g0[k] * dl[k];
+            u[3] += v1 * ndf; u[4] += v2 * ndf; u[5] += f0[k] * fd[k];
+        }
+        block_sum<6>(u, red);
+        // RFO: TR_calc(geometry, total_force_list = the biased GRADIENTS, rfo_delta)   (rfo_neb.py:181-184)
+        sc_rfo = tr_scale_interior(dnr, d1 / 2.0, d2 / 2.0, u[0], u[1], u[2] / (gnr * dnr));
+        // FIRE: TR_calc(geometry, projected NEB force, total_delta)                     (fire_neb.py:84-86)
+        sc_fire = tr_scale_interior(dnf, d1 / 2.0, d2 / 2.0, u[3], u[4], u[5] / (fnr * dnf));
+    }
+    double *out = newX + (size_t)loc * n;
+    double *rd = rfo_delta_out + (size_t)loc * n;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) {
+        const double rmv = (sc_rfo == 1.0) ? dl[k] : dl[k] * sc_rfo;
+        const double fmv = (sc_fire == 1.0) ? fd[k] : fd[k] * sc_fire;
+        // FIRE returns Angstrom; the blend converts back: tmp/bohr2ang - geometry (rfo_neb.py:193-194)
+        const double fire_move = ((x0[k] + fmv) * BOHR2ANG) / BOHR2ANG - x0[k];
+        const double mv = is_end ? -1.0 * rmv : (1.0 - ratio) * fire_move - ratio * rmv;
+        out[k] = (x0[k] + mv) * BOHR2ANG;
+        rd[k] = rmv;
+    }
+}
+
+}  // namespace mopt
+
+// ------------------------------------------------------------------------------------------
+struct mopt_band {
+    mopt_ctx *ctx = nullptr;
+    int I = 0, N = 0, n = 0, first = 0, count = 0;
+    double ratio = 0.5;
+    int fix_init = 0, fix_end = 0, apply_ts_opt = 1, apply_ci = 99999;
+    RsirfoWork wk;
+    double *X = nullptr, *G = nullptr, *E = nullptr, *pX = nullptr, *pG = nullptr, *F = nullptr, *pF = nullptr, *tau = nullptr;
+    double *gamma = nullptr, *rfo_delta = nullptr, *newX = nullptr, *wx = nullptr, *wg = nullptr;
+    void *block = nullptr;
+    bool have_prev = false, uploaded = false, opts_init = false, alloc_done = false;
+    std::vector<double> hE;
+};
+
+using namespace mopt;
+
+#define BTRY(x) do { int rc__ = (x); if (rc__ != MOPT_OK) return rc__; } while (0)
+
+static int band_alloc(mopt_band *b) {
+    mopt_ctx *ctx = b->ctx;
+    if (b->alloc_done) return MOPT_OK;
+    const size_t nv = (size_t)b->I * b->n * 8, cv = (size_t)b->count * b->n * 8;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const size_t tot = 7 * al(nv) + 2 * al((size_t)b->I * 8) + 2 * al(cv) + al((size_t)b->count * 8);
+    MOPT_HIP_TRY(ctx, hipMalloc(&b->block, tot));
+    MOPT_HIP_TRY(ctx, hipMemsetAsync(b->block, 0, tot, ctx->stream));
+    char *p = (char *)b->block;
+    auto take = [&](size_t x) { void *r = p; p += al(x); return (double *)r; };
+    b->X = take(nv); b->G = take(nv); b->pX = take(nv); b->pG = take(nv); b->F = take(nv); b->pF = take(nv); b->tau = take(nv);
+    b->E = take((size_t)b->I * 8); take((size_t)b->I * 8);
+    b->rfo_delta = take(cv); b->newX = take(cv); b->gamma = take((size_t)b->count * 8);
+    BTRY(b->wk.alloc(ctx, b->n, b->count, true, false, false));
+    // default Hessians: identity (rfo_neb.py:25)
+    std::vector<double> eye((size_t)b->n * b->n, 0.0);
+    for (int i = 0; i < b->n; ++i) eye[(size_t)i * b->n + i] = 1.0;
+    for (int k = 0; k < b->count; ++k)
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + (size_t)k * b->n * b->n, eye.data(), eye.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemsetAsync(b->wk.be, 0, (size_t)b->count * 8, ctx->stream));     // OPT.run(..., 0.0, 0.0, ...) (rfo_neb.py:166)
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->alloc_done = true;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_create(mopt_ctx *ctx, int I, int N, mopt_band **out) {
+    if (!ctx || !out) return MOPT_E_ARG;
+    *out = nullptr;
+    if (I < 3 || N < 1 || 3 * N > MOPT_MAX_N) { ctx->err = "mopt_band_create: need I >= 3 images and 1 <= N <= MOPT_MAX_N/3 atoms"; return MOPT_E_ARG; }
+    mopt_band *b = new (std::nothrow) mopt_band();
+    if (!b) return MOPT_E_NOMEM;
+    b->ctx = ctx; b->I = I; b->N = N; b->n = 3 * N; b->first = 0; b->count = I;
+    *out = b;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_destroy(mopt_band *b) {
+    if (!b) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    if (b->block) hipFree(b->block);
+    delete b;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_set_shard(mopt_band *b, int first, int count) {
+    if (!b) return MOPT_E_ARG;
+    if (b->alloc_done) { b->ctx->err = "mopt_band_set_shard must precede the first Hessian/upload call"; return MOPT_E_STATE; }
+    if (first < 0 || count < 1 || first + count > b->I) { b->ctx->err = "bad shard"; return MOPT_E_ARG; }
+    b->first = first; b->count = count;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_configure(mopt_band *b, double ratio, int fix_init_edge, int fix_end_edge, int apply_ts_opt, int apply_ci_neb) {
+    if (!b) return MOPT_E_ARG;
+    b->ratio = ratio; b->fix_init = fix_init_edge; b->fix_end = fix_end_edge; b->apply_ts_opt = apply_ts_opt; b->apply_ci = apply_ci_neb;
+    return MOPT_OK;
+}
+
+static int band_local(mopt_band *b, int image) {
+    if (image < b->first || image >= b->first + b->count) { b->ctx->err = "image not owned by this shard"; return -1; }
+    return image - b->first;
+}
+
+extern "C" int mopt_band_set_hessian(mopt_band *b, int image, const double *H) {
+    if (!b) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(band_alloc(b));
+    const int loc = band_local(b, image);
+    if (loc < 0) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    const size_t nn = (size_t)b->n * b->n;
+    if (H) {
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + loc * nn, H, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        std::vector<double> eye(nn, 0.0);
+        for (int i = 0; i < b->n; ++i) eye[(size_t)i * b->n + i] = 1.0;
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + loc * nn, eye.data(), nn * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_get_hessian(mopt_band *b, int image, double *H) {
+    if (!b || !H) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(band_alloc(b));
+    const int loc = band_local(b, image);
+    if (loc < 0) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    const size_t nn = (size_t)b->n * b->n;
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(H, b->wk.H + loc * nn, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_get_state(mopt_band *b, int image, mopt_rsirfo_state *out) {
+    if (!b || !out) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(band_alloc(b));
+    const int loc = band_local(b, image);
+    if (loc < 0) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(out, b->wk.states + loc, sizeof(mopt_rsirfo_state), hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_upload(mopt_band *b, const double *X, const double *E, const double *G) {
+    if (!b || !X || !E || !G) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(band_alloc(b));
+    mopt_ctx *ctx = b->ctx;
+    const size_t nv = (size_t)b->I * b->n * 8;
+    if (b->uploaded) {
+        // the inputs of the previous step become pre_geom / pre_gradient / pre_velocity (neb.py:594-600)
+        std::swap(b->X, b->pX); std::swap(b->G, b->pG); std::swap(b->F, b->pF);
+    }
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->X, X, nv, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->G, G, nv, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->E, E, (size_t)b->I * 8, hipMemcpyHostToDevice, ctx->stream));
+    b->hE.assign(E, E + b->I);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->uploaded = true;
+    return MOPT_OK;
+}
+
+static void band_default_params(mopt_rsirfo_params &p, bool is_end, bool neb_mode) {
+    // RSIRFO(method=..., saddle_order=0, trust_radius=...) defaults (rsirfo.py:26-91; rfo_neb.py:119-121)
+    p.alpha0 = 1.0; p.alpha_max = 1000.0; p.alpha_step_max = 10.0; p.small_eigval_thresh = 1e-6;
+    p.trust_radius_min = 0.01; p.trust_radius_max = 0.5;
+    p.good_step_threshold = 0.75; p.poor_step_threshold = 0.25;
+    p.trust_radius_increase_factor = 1.2; p.trust_radius_decrease_factor = 0.5;
+    p.energy_change_threshold = 1e-6; p.gradient_norm_threshold = 1e-4; p.step_norm_tolerance = 1e-3;
+    p.adaptive_trust_gradient_norm_threshold = 1e-2; p.max_curvature_factor = 2.5; p.negative_curvature_safety = 0.8;
+    p.level_shift_value = 1e-5; p.condition_number_threshold = 1e8;
+    p.max_micro_cycles = 40; p.saddle_order = 0;
+    p.rule = is_end ? MOPT_RULE_BLOCK_FSB : MOPT_RULE_BLOCK_BOFILL;
+    p.use_adaptive_trust_radius = 1; p.use_level_shift = 0; p.auto_level_shift = 1;
+    p.neb_mode = neb_mode ? 1 : 0; p.reserved = 0;
+}
+
+extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
+    if (!b) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    if (!b->uploaded) { ctx->err = "mopt_band_step: no inputs uploaded"; return MOPT_E_STATE; }
+    hipSetDevice(ctx->device);
+    const int I = b->I, N = b->N, n = b->n, first = b->first, count = b->count;
+    RsirfoWork &wk = b->wk;
+    if (optimize_num == 0 || !b->opts_init) {
+        // rfo_neb.py:112-127: fresh optimizer instances; interior images switch to NEB mode unless they are
+        // energy maxima and apply_ts_opt is set
+        std::vector<mopt_rsirfo_params> ps(count);
+        std::vector<mopt_rsirfo_state> ss(count);
+        std::vector<int> rules(count);
+        for (int k = 0; k < count; ++k) {
+            const int i = first + k;
+            const bool is_end = (i == 0 || i == I - 1);
+            const bool is_max = (!is_end) && b->hE[i] > b->hE[i - 1] && b->hE[i] > b->hE[i + 1];
+            band_default_params(ps[k], is_end, !is_end && !(is_max && b->apply_ts_opt));
+            std::memset((void *)&ss[k], 0, sizeof(mopt_rsirfo_state));
+            ss[k].trust_radius = is_end ? 0.5 : 0.2;
+            ss[k].prev_eigvec_size = -1;
+            rules[k] = ps[k].rule;
+        }
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.params, ps.data(), count * sizeof(mopt_rsirfo_params), hipMemcpyHostToDevice, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.states, ss.data(), count * sizeof(mopt_rsirfo_state), hipMemcpyHostToDevice, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.rules, rules.data(), count * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        b->opts_init = true;
+        b->have_prev = false;
+    }
+    const bool have_prev = b->have_prev && optimize_num != 0;
+    {
+        std::vector<int> upd(count, have_prev ? 1 : 0);
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.do_update, upd.data(), count * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // upd is a stack object
+    }
+    // 1. NEB force on the whole band (every shard needs all of F for FIRE's global switch)
+    BTRY(mopt_launch_bneb_force(ctx, I, N, 0, I, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau));
+    // 2. Ayala curvature correction of the owned interior images
+    {
+        mopt_scope sc(ctx, "neb_ayala", 2);
+        hipLaunchKernelGGL(k_gamma, dim3(count), dim3(256), 0, ctx->stream, I, n, first, b->X, b->E, b->G, b->tau, b->gamma);
+        hipLaunchKernelGGL(k_rank1, dim3((n + 7) / 8, count), dim3(256), 0, ctx->stream, n, first, b->gamma, b->tau, wk.H);
+    }
+    // 3. per-image RSIRFO.run with B_g = g = biased gradient, energies 0.0 (rfo_neb.py:159-166)
+    double *sx = wk.x, *sbg = wk.bg, *sg = wk.g, *spx = wk.px, *spg = wk.pg;
+    wk.x = b->X + (size_t)first * n; wk.bg = b->G + (size_t)first * n; wk.g = wk.bg;
+    wk.px = b->pX + (size_t)first * n; wk.pg = b->pG + (size_t)first * n;
+    int rc = mopt_rsirfo_pipeline(ctx, wk, n, count, have_prev, false, nullptr, wk.H);
+    wk.x = sx; wk.bg = sbg; wk.g = sg; wk.px = spx; wk.pg = spg;
+    if (rc != MOPT_OK) return rc;
+    // 4.-7. step limit, TR_calc, FIRE, blend
+    {
+        mopt_scope sc(ctx, "neb_post", 1);
+        hipLaunchKernelGGL(k_neb_post, dim3(count), dim3(128), (size_t)2 * n * 8, ctx->stream, I, N, first, optimize_num,
+                           have_prev ? 1 : 0, b->ratio, b->fix_init, b->fix_end, b->X, b->G, b->F, b->pF, wk.step, b->rfo_delta, b->newX);
+    }
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    b->have_prev = true;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_download(mopt_band *b, double *newX_angstrom, double *F, double *rfo_step) {
+    if (!b) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    hipSetDevice(ctx->device);
+    const size_t cv = (size_t)b->count * b->n * 8;
+    if (newX_angstrom) MOPT_HIP_TRY(ctx, hipMemcpyAsync(newX_angstrom, b->newX, cv, hipMemcpyDeviceToHost, ctx->stream));
+    if (F) MOPT_HIP_TRY(ctx, hipMemcpyAsync(F, b->F, (size_t)b->I * b->n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (rfo_step) MOPT_HIP_TRY(ctx, hipMemcpyAsync(rfo_step, b->rfo_delta, cv, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}

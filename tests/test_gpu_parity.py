@@ -174,3 +174,88 @@ def test_rsirfo_requires_hessian():
     opt = RSIRFO(method="rsirfo_bfgs", saddle_order=0)
     with pytest.raises(ValueError):
         opt.run(np.zeros((9, 1)), np.zeros((9, 1)))
+
+
+@pytest.mark.parametrize("variant", ["ident", "exact"])
+def test_rfo_neb_band_steps_vs_reference(variant):
+    """G7: four consecutive RFOOptimizer.optimize steps (I = 8, N = 7) incl. the accumulated per-image Hessians."""
+    from multioptpy_amd.band import Band
+    z = np.load(os.path.join(G, "g7_neb_step.npz"))
+    I, N = 8, 7
+    X0 = z[f"{variant}_it0_X"]
+    band = Band(I, N)
+    if variant == "exact":
+        for i in range(I):
+            band.set_hessian(i, cases.lj(X0[i], hessian=True)[2])
+    for it in range(4):
+        tag = f"{variant}_it{it}"
+        X, E, Gr = z[tag + "_X"], z[tag + "_E"], z[tag + "_G"]
+        band.upload(X, E, Gr)
+        band.step(it)
+        newX, F = band.download(want_force=True)
+        assert np.abs(F - z[tag + "_F"]).max() < 1e-12, tag
+        err = np.abs(newX - z[tag + "_newX"]).max()
+        assert err < 1e-8, (tag, err)
+        H = np.array([band.get_hessian(i) for i in range(I)])
+        assert np.abs(H - z[tag + "_hess"]).max() < 1e-8, (tag, np.abs(H - z[tag + "_hess"]).max())
+        tr = np.array([band.get_state(i).trust_radius for i in range(I)])
+        assert np.allclose(tr, z[tag + "_tr"], atol=1e-12), tag
+    band.close()
+
+
+def test_rfo_optimizer_class_with_npy_persistence(tmp_path):
+    """The drop-in class under the reference's calling convention, Hessians round-tripping through tmp_hessian_i.npy."""
+    from multioptpy_amd.Optimizer.rfo_neb import RFOOptimizer
+    from multioptpy_amd.MEP.pathopt_bneb_force import CaluculationBNEB
+    z = np.load(os.path.join(G, "g7_neb_step.npz"))
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.NEB_FOLDER_DIRECTORY = str(tmp_path) + "/"
+    cfg.fix_init_edge = cfg.fix_end_edge = False
+    cfg.ratio_of_rfo_step = 0.5
+    I = 8
+    X0 = z["exact_it0_X"]
+    for i in range(I):
+        np.save(cfg.NEB_FOLDER_DIRECTORY + f"tmp_hessian_{i}.npy", cases.lj(X0[i], hessian=True)[2])
+    opt = RFOOptimizer(cfg)
+    calc = CaluculationBNEB()
+    preX = preG = None
+    pre_vel = []
+    for it in range(3):
+        tag = f"exact_it{it}"
+        X, E, Gr = z[tag + "_X"], z[tag + "_E"], z[tag + "_G"]
+        F = calc.calc_force(X, E, Gr, it, ["Ar"] * 7)
+        assert np.abs(F - z[tag + "_F"]).max() < 1e-12
+        newX = opt.optimize(X, Gr, preX, preG, it, E, E, pre_vel, F.copy(), None, preX, calc)
+        assert np.abs(newX - z[tag + "_newX"]).max() < 1e-8, tag
+        H = np.array([np.load(cfg.NEB_FOLDER_DIRECTORY + f"tmp_hessian_{i}.npy") for i in range(I)])
+        assert np.abs(H - z[tag + "_hess"]).max() < 1e-8
+        preX, preG, pre_vel = X.copy(), Gr.copy(), F.copy()
+
+
+def test_band_sharded_matches_whole():
+    """Image sharding: two shards of a 10-image band reproduce the single-shard result (no data-path collective:
+    every shard sees the whole X/E/G and owns the RSIRFO work of its images)."""
+    from multioptpy_amd.band import Band
+    I, N = 10, 9
+    X = cases.band(I, N)
+    whole = Band(I, N)
+    parts = [Band(I, N, first=0, count=5), Band(I, N, first=5, count=5)]
+    for it in range(3):
+        E = np.zeros(I)
+        Gr = np.zeros((I, N, 3))
+        for i in range(I):
+            E[i], Gr[i] = cases.lj(X[i])
+        whole.upload(X, E, Gr)
+        whole.step(it)
+        ref = whole.download()
+        got = []
+        for p in parts:
+            p.upload(X, E, Gr)
+            p.step(it)
+            got.append(p.download())
+        got = np.concatenate(got, axis=0)
+        assert np.array_equal(got, ref)
+        X = ref / cases.BOHR2ANG
