@@ -180,6 +180,11 @@ int mopt_band_upload(mopt_band *band, const double *X, const double *E, const do
  * the reference returns it) on the device; the previous inputs become pre_geom / pre_gradient. */
 int mopt_band_step(mopt_band *band, int optimize_num);
 int mopt_band_download(mopt_band *band, double *newX_angstrom, double *F, double *rfo_step);
+/* Same as upload / download with DEVICE pointers (inputs already resident in HBM, e.g. produced by a GPU
+ * calculator or staged ahead of time); E_host (I doubles, host) is only read when a step re-creates the
+ * optimizer instances (optimize_num == 0) and may be NULL otherwise.  Copies are stream-ordered on the ctx. */
+int mopt_band_upload_dev(mopt_band *band, const double *dX, const double *dE, const double *dG, const double *E_host);
+int mopt_band_download_dev(mopt_band *band, double *d_newX_angstrom);
 
 #ifdef __cplusplus
 }

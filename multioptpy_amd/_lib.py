@@ -52,6 +52,8 @@ def _proto(lib):
         lib.mopt_band_upload.argtypes = [vp, DP, DP, DP]
         lib.mopt_band_step.argtypes = [vp, C.c_int]
         lib.mopt_band_download.argtypes = [vp, DP, DP, DP]
+        lib.mopt_band_upload_dev.argtypes = [vp, vp, vp, vp, DP]
+        lib.mopt_band_download_dev.argtypes = [vp, vp]
 
 
 def lib():

@@ -54,6 +54,23 @@ class Band:
         E = f64(E).reshape(self.I)
         check(lib().mopt_band_upload(self._h, ptr(X), ptr(E), ptr(G)), self._ctx)
 
+    def upload_dev(self, dX, dE, dG, E_host=None):
+        """Device pointers (ints, e.g. torch.Tensor.data_ptr()) of X (I,N,3), E (I), G (I,N,3) float64."""
+        Eh = None if E_host is None else f64(E_host).reshape(self.I)
+        check(lib().mopt_band_upload_dev(self._h, C.c_void_p(int(dX)), C.c_void_p(int(dE)), C.c_void_p(int(dG)), ptr(Eh)), self._ctx)
+
+    def download_dev(self, d_newX):
+        check(lib().mopt_band_download_dev(self._h, C.c_void_p(int(d_newX))), self._ctx)
+
+    def timing(self, enable):
+        check(lib().mopt_ctx_timing(self._ctx, int(bool(enable))), self._ctx)
+
+    def timing_read(self, family):
+        ms = C.c_double(0.0)
+        nl = C.c_int64(0)
+        check(lib().mopt_ctx_timing_read(self._ctx, family.encode(), C.byref(ms), C.byref(nl)), self._ctx)
+        return ms.value, nl.value
+
     def step(self, optimize_num):
         check(lib().mopt_band_step(self._h, int(optimize_num)), self._ctx)
 

@@ -452,3 +452,26 @@ extern "C" int mopt_band_download(mopt_band *b, double *newX_angstrom, double *F
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MOPT_OK;
 }
+
+extern "C" int mopt_band_upload_dev(mopt_band *b, const double *dX, const double *dE, const double *dG, const double *E_host) {
+    if (!b || !dX || !dE || !dG) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(band_alloc(b));
+    mopt_ctx *ctx = b->ctx;
+    const size_t nv = (size_t)b->I * b->n * 8;
+    if (b->uploaded) { std::swap(b->X, b->pX); std::swap(b->G, b->pG); std::swap(b->F, b->pF); }
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->X, dX, nv, hipMemcpyDeviceToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->G, dG, nv, hipMemcpyDeviceToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->E, dE, (size_t)b->I * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (E_host) b->hE.assign(E_host, E_host + b->I);
+    b->uploaded = true;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_download_dev(mopt_band *b, double *d_newX) {
+    if (!b || !d_newX) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    hipSetDevice(ctx->device);
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(d_newX, b->newX, (size_t)b->count * b->n * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    return MOPT_OK;
+}
