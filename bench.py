@@ -116,9 +116,8 @@ def main():
     I, N = args.images, args.atoms
     n = 3 * N
     W, K = max(1, args.warmup), args.steps
-    assert I % world == 0, "images must divide evenly over the ranks"
-    count = I // world
-    first = rank * count
+    from multioptpy_amd.parallel import shard_bounds, gather_band
+    first, count = shard_bounds(I, world, rank)
 
     # ---- inputs for every step, staged in HBM (untimed)
     traj = make_trajectory(I, N, W + K, local)
@@ -128,7 +127,6 @@ def main():
 
     def run(band, timing=False):
         newx_t = torch.empty((count, N, 3), dtype=torch.float64, device=dev)
-        full_t = torch.empty((I, N, 3), dtype=torch.float64, device=dev) if world > 1 else None
         for k in range(W):
             dX, dE, dG = staged[k]
             band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), traj[k][1])
@@ -147,7 +145,7 @@ def main():
             if world > 1:
                 band.download_dev(newx_t.data_ptr())
                 band.sync()
-                dist.all_gather_into_tensor(full_t, newx_t)
+                gather_band(newx_t, I)
         band.sync()
         torch.cuda.synchronize()
         if world > 1:
