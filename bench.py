@@ -159,21 +159,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / K
-    last_new = band.download()
     sweeps = [band.get_state(first + j).jacobi_sweeps for j in range(count)]
     band.close()
 
     roofline = None
     fam = {}
+    # ---- roofline leg: the same K steps again on a fresh band with HIP-event timing per kernel family
+    # (every rank runs it -- run() contains barriers -- but only rank 0 records and reports)
+    b2 = Band(I, N, first=first, count=count, device=local)
+    run(b2, timing=(rank == 0))
     if rank == 0:
-        # ---- roofline leg: the same K steps again on a fresh band with HIP-event timing per kernel family
-        b2 = Band(I, N, first=first, count=count, device=local)
-        run(b2, timing=True)
         for name in ("hess_update", "project", "eigh_init", "eigh_jacobi", "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post"):
             ms, nl = b2.timing_read(name)
             fam[name] = {"ms_per_step": ms / K, "launches_per_step": nl / K}
         b2.timing(False)
-        b2.close()
         dom = max(fam, key=lambda k: fam[k]["ms_per_step"])
         # algorithmic bytes: 80 n^2 per image-step for the whole RSIRFO.run, of which the eigen-solve's share
         # (input read + eigenvector write) is 16 n^2; flops_alg = (20/3) n^3 + 40 n^2 per image-step.
@@ -193,6 +192,8 @@ def main():
                            "fp64_frac": (flops_step / (step_kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if step_kernel_ms > 0 else 0.0},
             "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
         }
+
+    b2.close()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
