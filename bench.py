@@ -106,10 +106,16 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    backend = os.environ.get("MOPT_BENCH_BACKEND", "nccl")      # "gloo" + MOPT_BENCH_SHARE_GPU=1: rehearsal on a 1-GPU box
+    if os.environ.get("MOPT_BENCH_SHARE_GPU", "0") == "1":
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     import cases
     from multioptpy_amd.band import Band
@@ -155,7 +161,7 @@ def main():
     band = Band(I, N, first=first, count=count, device=local)
     elapsed = run(band)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / K

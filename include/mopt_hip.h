@@ -88,6 +88,10 @@ int mopt_project_trrot_grad(mopt_ctx *ctx, int n, int batch, const double *g, co
  * sweeps_out (may be NULL) receives the Jacobi sweep count per matrix. */
 int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, double *W, double *V, int *sweeps_out);
 
+/* C = A B for batch x n x n row-major matrices on the FP64 matrix cores (np.dot call sites such as
+ * rsirfo.py:423,927,940; used internally to warm-start the eigen-solver from the previous eigenvectors). */
+int mopt_dgemm(mopt_ctx *ctx, int n, int batch, const double *A, const double *B, double *C);
+
 /* ---- RSIRFO.run (multioptpy/Optimizer/rsirfo.py:285-490), batched ---------------------- */
 
 typedef struct mopt_rsirfo_params {

@@ -4,6 +4,7 @@
 //   k_rank1     H += gamma t t^T (rfo_neb.py:72)
 //   k_neb_post  step limit (rfo_neb.py:76-83) -> TR_calc (trust_radius_neb.py:17-98) -> FIRE (fire_neb.py:38-92)
 //               -> blend and Bohr->Angstrom (rfo_neb.py:193-206)
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -230,6 +231,9 @@ struct mopt_band {
     double *gamma = nullptr, *rfo_delta = nullptr, *newX = nullptr, *wx = nullptr, *wg = nullptr;
     void *block = nullptr;
     bool have_prev = false, uploaded = false, opts_init = false, alloc_done = false;
+    bool have_vecs = false;          // wk.Vt holds the eigenvectors of the previous step (warm start)
+    int warm_run = 0;                // consecutive warm-started solves (a cold solve every 64 re-orthogonalises V)
+    int warm_enabled = 1;
     std::vector<double> hE;
 };
 
@@ -292,6 +296,7 @@ extern "C" int mopt_band_set_shard(mopt_band *b, int first, int count) {
 
 extern "C" int mopt_band_configure(mopt_band *b, double ratio, int fix_init_edge, int fix_end_edge, int apply_ts_opt, int apply_ci_neb) {
     if (!b) return MOPT_E_ARG;
+    if (const char *e = getenv("MOPT_EIGH_WARM")) b->warm_enabled = atoi(e);
     b->ratio = ratio; b->fix_init = fix_init_edge; b->fix_end = fix_end_edge; b->apply_ts_opt = apply_ts_opt; b->apply_ci = apply_ci_neb;
     return MOPT_OK;
 }
@@ -408,6 +413,7 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
         MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         b->opts_init = true;
         b->have_prev = false;
+        b->have_vecs = false;
     }
     const bool have_prev = b->have_prev && optimize_num != 0;
     {
@@ -427,7 +433,10 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
     double *sx = wk.x, *sbg = wk.bg, *sg = wk.g, *spx = wk.px, *spg = wk.pg;
     wk.x = b->X + (size_t)first * n; wk.bg = b->G + (size_t)first * n; wk.g = wk.bg;
     wk.px = b->pX + (size_t)first * n; wk.pg = b->pG + (size_t)first * n;
-    int rc = mopt_rsirfo_pipeline(ctx, wk, n, count, have_prev, false, nullptr, wk.H);
+    const bool warm = b->warm_enabled && b->have_vecs && b->warm_run < 64;
+    int rc = mopt_rsirfo_pipeline(ctx, wk, n, count, have_prev, false, nullptr, wk.H, warm);
+    b->warm_run = warm ? b->warm_run + 1 : 0;
+    b->have_vecs = true;
     wk.x = sx; wk.bg = sbg; wk.g = sg; wk.px = spx; wk.pg = spg;
     if (rc != MOPT_OK) return rc;
     // 4.-7. step limit, TR_calc, FIRE, blend

@@ -52,6 +52,10 @@ __global__ void k_jac_init(int n, const double *__restrict__ A, const double *__
     if (blockIdx.x == 0 && threadIdx.x <= JAC_MAX_SWEEPS) rotcount[b * (JAC_MAX_SWEEPS + 1) + threadIdx.x] = 0;
 }
 
+__global__ void k_jac_clear(int *__restrict__ rotcount) {
+    if (threadIdx.x <= JAC_MAX_SWEEPS) rotcount[blockIdx.x * (JAC_MAX_SWEEPS + 1) + threadIdx.x] = 0;
+}
+
 // One outer tournament step.  grid = (nb/2, batch); block = 64 * bw threads; dynamic LDS = 2 * (2 bw) * n doubles.
 // sweep >= 1: returns at once when the previous sweep applied no rotation to this matrix.
 __global__ void k_jac_step(int n, int bw, int nb, int tstep, int sweep, double tol, double *__restrict__ Gt_,
@@ -229,7 +233,7 @@ int mopt_jacobi_block_width(const mopt_ctx *ctx, int n) {
 }
 
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
-                     int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps) {
+                     int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps, bool warm) {
     using namespace mopt;
     const int bw = mopt_jacobi_block_width(ctx, n);
     if (bw == 0) { ctx->err = "mopt_eigh: n too large for the LDS-resident Jacobi panels"; return MOPT_E_ARG; }
@@ -238,15 +242,24 @@ int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double 
     if (nb < 2) nb = 2;
     const size_t lds = (size_t)2 * (2 * bw) * n * sizeof(double);
     if (!g_jac_lds_attr_done) {
-        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_jac_step, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_jac_step, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
         g_jac_lds_attr_done = 1;
     }
     if (max_sweeps > JAC_MAX_SWEEPS) max_sweeps = JAC_MAX_SWEEPS;
-    const double tol = fmax(1e-14, 2.0 * sqrt((double)n) * 2.220446049250313e-16);
+    // relative column-orthogonality threshold: the rounding noise of a length-n dot product is ~ sqrt(n) eps; 1e-13 keeps
+    // the eigenvalue error at a few eps ||A|| and the residual at 1e-13 ||A|| and saves the last borderline sweep
+    const double tol = fmax(1e-13, 4.0 * sqrt((double)n) * 2.220446049250313e-16);
     {
         mopt_scope sc(ctx, "eigh_init", 2);
         hipLaunchKernelGGL(k_jac_sigma, dim3(batch), dim3(256), 0, ctx->stream, n, d_A, d_sigma);
-        hipLaunchKernelGGL(k_jac_init, dim3(64, batch), dim3(256), 0, ctx->stream, n, d_A, d_sigma, d_Gt, d_Vt, d_rotcount);
+        if (warm) {
+            // Vt holds the previous step's eigenvectors: Gt = Vt (A + sigma I) on the matrix cores, rotation counters cleared
+            hipLaunchKernelGGL(k_jac_clear, dim3(batch), dim3(64), 0, ctx->stream, d_rotcount);
+            int rc = mopt_launch_dgemm(ctx, n, batch, d_Vt, d_A, d_sigma, d_Gt);
+            if (rc != MOPT_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(k_jac_init, dim3(64, batch), dim3(256), 0, ctx->stream, n, d_A, d_sigma, d_Gt, d_Vt, d_rotcount);
+        }
     }
     {
         mopt_scope sc(ctx, "eigh_jacobi", max_sweeps * (nb - 1));

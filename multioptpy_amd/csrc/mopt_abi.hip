@@ -160,13 +160,27 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     TRY(dW.alloc(ctx, nv)); TRY(dperm.alloc(ctx, (size_t)batch * n * sizeof(int))); TRY(dinfo.alloc(ctx, (size_t)batch * 2 * sizeof(int)));
     H2D(ctx, dA.p, A, nn);
     TRY(mopt_launch_eigh(ctx, n, batch, dA.as<double>(), dsig.as<double>(), dG.as<double>(), dVt.as<double>(), drot.as<int>(),
-                         dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), MOPT_DEFAULT_SWEEPS));
+                         dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), MOPT_DEFAULT_SWEEPS, false));
     TRY(mopt_launch_eig_gather(ctx, n, batch, dVt.as<double>(), dperm.as<int>(), dV.as<double>()));
     D2H(ctx, W, dW.p, nv); D2H(ctx, V, dV.p, nn);
     std::vector<int> info(2 * batch);
     D2H(ctx, info.data(), dinfo.p, (size_t)batch * 2 * sizeof(int));
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (sweeps_out) for (int b = 0; b < batch; ++b) sweeps_out[b] = info[2 * b];
+    return MOPT_OK;
+}
+
+extern "C" int mopt_dgemm(mopt_ctx *ctx, int n, int batch, const double *A, const double *B, double *C) {
+    if (!ctx) return MOPT_E_ARG;
+    if (n < 1 || batch < 1 || !A || !B || !C) { ctx->err = "mopt_dgemm: bad arguments"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    const size_t nn = (size_t)batch * n * n * sizeof(double);
+    DBuf dA, dB, dC;
+    TRY(dA.alloc(ctx, nn)); TRY(dB.alloc(ctx, nn)); TRY(dC.alloc(ctx, nn));
+    H2D(ctx, dA.p, A, nn); H2D(ctx, dB.p, B, nn);
+    TRY(mopt_launch_dgemm(ctx, n, batch, dA.as<double>(), dB.as<double>(), nullptr, dC.as<double>()));
+    D2H(ctx, C, dC.p, nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return MOPT_OK;
 }
 

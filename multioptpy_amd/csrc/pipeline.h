@@ -32,7 +32,7 @@ struct RsirfoWork {
 
 // update (optional) -> TR/rot projections -> eigh -> RS-I-RFO step.  Hsym may alias wk.H (in-place).
 int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
-                         double *d_Hinpl, double *d_Hsym);
+                         double *d_Hinpl, double *d_Hsym, bool warm_eigh = false);
 
 // launchers (defined next to their kernels)
 int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules, const int *d_do_update, bool any_flowchart,
@@ -45,7 +45,8 @@ int mopt_launch_project_hess(mopt_ctx *ctx, int n, int batch, const double *d_H,
 int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp);
 int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
-                     int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps);
+                     int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps, bool warm);
+int mopt_launch_dgemm(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_B, const double *d_addscale, double *d_C);
 int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const int *d_perm, double *d_V);
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,

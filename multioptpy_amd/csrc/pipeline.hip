@@ -42,7 +42,7 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
 }
 
 int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
-                         double *d_Hinpl, double *d_Hsym) {
+                         double *d_Hinpl, double *d_Hsym, bool warm_eigh) {
     int rc;
     const mopt::UpdateCoef *coef = nullptr;
     if (any_update) {
@@ -55,7 +55,7 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     if (rc != MOPT_OK) return rc;
     rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A);
     if (rc != MOPT_OK) return rc;
-    rc = mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS);
+    rc = mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm_eigh);
     if (rc != MOPT_OK) return rc;
     rc = mopt_launch_rfo(ctx, n, batch, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, wk.gp, wk.bg, wk.be, coef,
                          wk.gt_all, wk.coefout, wk.step);

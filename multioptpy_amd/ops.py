@@ -72,3 +72,14 @@ def bneb_force(X, E, G, optimize_num=0, apply_ci_neb=99999):
     c = ctx()
     check(lib().mopt_bneb_force(c, I, N, ptr(X), ptr(E), ptr(G), int(optimize_num), int(apply_ci_neb), ptr(F), ptr(tau)), c)
     return F, tau
+
+
+def dgemm(A, B):
+    A = f64(A)
+    B = f64(B)
+    A3 = A.reshape((-1,) + A.shape[-2:])
+    B3 = B.reshape((-1,) + B.shape[-2:])
+    out = np.empty_like(A3)
+    c = ctx()
+    check(lib().mopt_dgemm(c, A3.shape[1], A3.shape[0], ptr(A3), ptr(B3), ptr(out)), c)
+    return out.reshape(A.shape)

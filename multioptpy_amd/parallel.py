@@ -20,6 +20,12 @@ def gather_band(local_new, n_images):
     """All-gather the per-rank blocks (count, N, 3) into the whole band (I, N, 3), in image order."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local_new
+    if dist.get_backend() == "gloo":
+        # CPU rehearsal path (tests, single-GPU boxes): gloo has no all_gather_into_tensor for device tensors
+        src = local_new.detach().cpu().contiguous()
+        parts = [torch.empty_like(src) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, src)
+        return torch.cat(parts, dim=0).to(local_new.device)
     out = torch.empty((n_images,) + tuple(local_new.shape[1:]), dtype=local_new.dtype, device=local_new.device)
     dist.all_gather_into_tensor(out, local_new.contiguous())
     return out

@@ -259,3 +259,41 @@ def test_band_sharded_matches_whole():
         got = np.concatenate(got, axis=0)
         assert np.array_equal(got, ref)
         X = ref / cases.BOHR2ANG
+
+
+@pytest.mark.parametrize("n", [5, 64, 100, 300])
+def test_dgemm_mfma_f64(ops, n):
+    rng = np.random.default_rng(n)
+    A = rng.normal(size=(3, n, n))
+    B = rng.normal(size=(3, n, n))          # asymmetric on purpose: catches a transposed operand / C write
+    C = ops.dgemm(A, B)
+    ref = A @ B
+    assert np.abs(C - ref).max() < 1e-12 * n
+
+
+def test_band_warm_start_matches_cold():
+    """Warm-starting the Jacobi eigen-solver from the previous step's eigenvectors changes only the gauge."""
+    import os as _os
+    from multioptpy_amd.band import Band
+    I, N = 6, 12
+    res = {}
+    for warm in ("1", "0"):
+        _os.environ["MOPT_EIGH_WARM"] = warm
+        band = Band(I, N)
+        X = cases.band(I, N)
+        outs = []
+        for it in range(5):
+            E = np.zeros(I)
+            Gr = np.zeros((I, N, 3))
+            for i in range(I):
+                E[i], Gr[i] = cases.lj(X[i])
+            band.upload(X, E, Gr)
+            band.step(it)
+            new = band.download()
+            outs.append(new)
+            X = new / cases.BOHR2ANG
+        res[warm] = (np.array(outs), [band.get_state(i).jacobi_sweeps for i in range(I)])
+        band.close()
+    _os.environ.pop("MOPT_EIGH_WARM", None)
+    assert np.abs(res["1"][0] - res["0"][0]).max() < 1e-9
+    print("sweeps warm", res["1"][1], "cold", res["0"][1])
