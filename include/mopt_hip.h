@@ -160,6 +160,15 @@ int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *p
 int mopt_bneb_force(mopt_ctx *ctx, int I, int N, const double *X, const double *E, const double *G,
                     int optimize_num, int apply_ci_neb, double *F, double *tau);
 
+/* The spring / tangent variants of nebmain (neb.py:769-792), same arguments (tau only exists for BNEB and may be NULL):
+ *   MOPT_NEB_BNEB   CaluculationBNEB   pathopt_bneb_force.py:21-117    (default; == mopt_bneb_force)
+ *   MOPT_NEB_BNEB3  CaluculationBNEB3  pathopt_bneb_force.py:305-356   (-bneb2: + next-nearest-neighbour springs)
+ *   MOPT_NEB_EWBNEB CaluculationEWBNEB pathopt_ewbneb_force.py:21-117  (-ewbneb: + energy-weighted springs)
+ *   MOPT_NEB_DNEB   CaluculationDNEB   pathopt_dneb_force.py:20-130    (-dneb: per-atom tangents, doubly nudged) */
+enum { MOPT_NEB_BNEB = 0, MOPT_NEB_BNEB3 = 1, MOPT_NEB_EWBNEB = 2, MOPT_NEB_DNEB = 3 };
+int mopt_neb_force(mopt_ctx *ctx, int variant, int I, int N, const double *X, const double *E, const double *G,
+                   int optimize_num, int apply_ci_neb, double *F, double *tau);
+
 /* Device-resident band: the per-image Hessians and RSIRFO instances of RFOOptimizer
  * (multioptpy/Optimizer/rfo_neb.py:86-208) stay in HBM between steps instead of going
  * through tmp_hessian_{i}.npy (rfo_neb.py:18-25,175). */

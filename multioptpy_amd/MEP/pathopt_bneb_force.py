@@ -29,3 +29,18 @@ class CaluculationBNEB:
         if len(self.tau_list) == 0:
             raise ValueError("Tangent list is empty. Calculate forces first.")
         return self.tau_list[node_num]
+
+
+class CaluculationBNEB3:
+    """Drop-in for ``multioptpy.MEP.pathopt_bneb_force.CaluculationBNEB3`` (reference :305-356; nebmain ``-bneb2``)."""
+
+    def __init__(self, APPLY_CI_NEB=99999):
+        self.APPLY_CI_NEB = APPLY_CI_NEB
+        self.spring_force_const = 0.05
+
+    def calc_ci_neb_force(self, grad, tangent_grad):
+        return -2.0 * tangent_grad
+
+    def calc_force(self, geometry_num_list, energy_list, gradient_list, optimize_num, element_list):
+        return ops.neb_force("bneb3", np.asarray(geometry_num_list, dtype=np.float64), np.asarray(energy_list, dtype=np.float64),
+                             np.asarray(gradient_list, dtype=np.float64), optimize_num, self.APPLY_CI_NEB)

@@ -40,6 +40,7 @@ def _proto(lib):
     lib.mopt_eigh.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, IP]
     lib.mopt_dgemm.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP]
     lib.mopt_bneb_force.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, C.c_int, C.c_int, DP, DP]
+    lib.mopt_neb_force.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, C.c_int, C.c_int, DP, DP]
     lib.mopt_rsirfo_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),
                                     DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_band_create"):

@@ -200,6 +200,27 @@ extern "C" int mopt_bneb_force(mopt_ctx *ctx, int I, int N, const double *X, con
     return MOPT_OK;
 }
 
+extern "C" int mopt_neb_force(mopt_ctx *ctx, int variant, int I, int N, const double *X, const double *E, const double *G,
+                              int optimize_num, int apply_ci_neb, double *F, double *tau) {
+    if (!ctx) return MOPT_E_ARG;
+    if (variant == MOPT_NEB_BNEB) {
+        if (!tau) { ctx->err = "mopt_neb_force: BNEB needs a tau buffer"; return MOPT_E_ARG; }
+        return mopt_bneb_force(ctx, I, N, X, E, G, optimize_num, apply_ci_neb, F, tau);
+    }
+    if (variant < 0 || variant > MOPT_NEB_DNEB || I < 2 || N < 1 || !X || !E || !G || !F) { ctx->err = "mopt_neb_force: bad arguments"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    const size_t nv = (size_t)I * N * 3 * sizeof(double);
+    DBuf dX, dE, dG, dF;
+    TRY(dX.alloc(ctx, nv)); TRY(dE.alloc(ctx, I * sizeof(double))); TRY(dG.alloc(ctx, nv)); TRY(dF.alloc(ctx, nv));
+    H2D(ctx, dX.p, X, nv); H2D(ctx, dE.p, E, I * sizeof(double)); H2D(ctx, dG.p, G, nv);
+    // CI switch: BNEB-type classes test `optimize_num > APPLY_CI_NEB`, DNEB `APPLY_CI_NEB < optimize_num` (the same)
+    TRY(mopt_launch_neb_force_var(ctx, variant, I, N, 0, I, dX.as<double>(), dE.as<double>(), dG.as<double>(),
+                                  optimize_num > apply_ci_neb ? 1 : 0, dF.as<double>()));
+    D2H(ctx, F, dF.p, nv);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // RSIRFO.run on host buffers
 // ------------------------------------------------------------------------------------------

@@ -52,5 +52,7 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,
                     const double *d_Bg, const double *d_Be, const mopt::UpdateCoef *d_coef, double *d_gt_all,
                     double *d_coefout, double *d_step);
+int mopt_launch_neb_force_var(mopt_ctx *ctx, int variant, int I, int N, int first, int count, const double *d_X, const double *d_E,
+                              const double *d_G, int ci_active, double *d_F);
 int mopt_launch_bneb_force(mopt_ctx *ctx, int I, int N, int first, int count, const double *d_X, const double *d_E,
                            const double *d_G, int ci_active, double *d_F, double *d_tau);

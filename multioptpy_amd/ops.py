@@ -83,3 +83,21 @@ def dgemm(A, B):
     c = ctx()
     check(lib().mopt_dgemm(c, A3.shape[1], A3.shape[0], ptr(A3), ptr(B3), ptr(out)), c)
     return out.reshape(A.shape)
+
+
+NEB_VARIANTS = {"bneb": 0, "bneb3": 1, "ewbneb": 2, "dneb": 3}
+
+
+def neb_force(variant, X, E, G, optimize_num=0, apply_ci_neb=99999):
+    """calc_force of the NEB force classes; returns (F, tau) for "bneb", F otherwise."""
+    v = NEB_VARIANTS[variant]
+    if v == 0:
+        return bneb_force(X, E, G, optimize_num, apply_ci_neb)
+    X = f64(X)
+    I, N = X.shape[0], X.shape[1]
+    E = f64(E)
+    G = f64(G)
+    F = np.empty_like(X)
+    c = ctx()
+    check(lib().mopt_neb_force(c, v, I, N, ptr(X), ptr(E), ptr(G), int(optimize_num), int(apply_ci_neb), ptr(F), None), c)
+    return F

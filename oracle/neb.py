@@ -309,3 +309,143 @@ class RFONEB:
             else:
                 out.append((1.0 - self.ratio) * fire_mv[i] - self.ratio * rfo_mv[i])
         return (X + np.array(out, dtype=float)) * BOHR2ANG
+
+
+# ---------------------------------------------------------------------------------------------
+# spring variants
+# ---------------------------------------------------------------------------------------------
+class BNEB3(BNEB):
+    """CaluculationBNEB3 (pathopt_bneb_force.py:305-356): BNEB projection (no CI switches) + next-nearest springs."""
+
+    def __init__(self, APPLY_CI_NEB=99999, literal=False):
+        super().__init__(APPLY_CI_NEB, literal)
+        self.k = 0.05
+
+    def calc_force(self, X, E, G, optimize_num, element_list=None):
+        I = len(E)
+        F = []
+        nrm = np.linalg.norm
+        for i in range(I):
+            if i == 0 or i == I - 1:
+                F.append(-1 * np.array(G[i], dtype=float))
+                continue
+            force, _ = self._project(X[i - 1], X[i], X[i + 1], np.array(G[i], dtype=float), E[i - 1:i + 2])
+            if 1 < i < I - 2:
+                c0, c1, c2, c3, c4 = X[i - 2], X[i - 1], X[i], X[i + 1], X[i + 2]
+                f1 = self.k * (nrm(c1 - c2) - nrm(c0 - c1)) * (c1 - c2) / (nrm(c1 - c2) + 1e-15)
+                f2 = self.k * (nrm(c2 - c3) - nrm(c1 - c2)) * (-1 * (c1 - c2) / (nrm(c1 - c2) + 1e-15) - (c2 - c3) / (nrm(c2 - c3) + 1e-15))
+                f3 = self.k * (nrm(c3 - c4) - nrm(c2 - c3)) * (c3 - c4) / (nrm(c3 - c4) + 1e-15)
+                spring = f1 + f2 + f3
+            else:
+                spring = 0.0 * force
+            F.append(-1 * force.reshape(-1, 3) - 1 * spring.reshape(-1, 3))
+        return np.array(F, dtype=float)
+
+
+class EWBNEB(BNEB):
+    """CaluculationEWBNEB (pathopt_ewbneb_force.py:21-117): BNEB projection + energy-weighted springs along the
+    whole-image unit vectors to the neighbours."""
+
+    upper, lower = 0.005, 0.0001
+
+    def calc_force(self, X, E, G, optimize_num, element_list=None):
+        I = len(E)
+        maxima, _ = extremum_list_index(E)
+        max_ene = max(E)
+        ref = E[-1] if E[0] > E[-1] else E[0]
+        ks = []
+        for i in range(I):
+            if i == 0 or i == I - 1:
+                ks.append(0.0)
+                continue
+            den = max_ene - ref
+            if den < 1e-8:
+                den = 1e-8
+            alpha = (E[i] - ref) / den
+            if E[i] < ref:
+                ks.append(self.lower)
+            elif E[i] > ref:
+                ks.append(self.upper * (1.0 - alpha) + alpha * self.lower)
+            else:
+                ks.append(0.0)
+        F = []
+        for i in range(I):
+            if i == 0 or i == I - 1:
+                F.append(-1 * np.array(G[i], dtype=float))
+                continue
+            force, tg = self._project(X[i - 1], X[i], X[i + 1], np.array(G[i], dtype=float), E[i - 1:i + 2])
+            if optimize_num > self.APPLY_CI_NEB and (i + 1 in maxima or i - 1 in maxima) and (i != 1 and i != I - 2):
+                force = force * 0.001
+            elif optimize_num > self.APPLY_CI_NEB and (i in maxima) and (i != 1 or i != I - 2):
+                force = -2.0 * tg
+            fwd = X[i + 1] - X[i]
+            bwd = X[i] - X[i - 1]
+            nf, nb = np.linalg.norm(fwd), np.linalg.norm(bwd)
+            uf = fwd / nf if nf > 1e-8 else np.zeros_like(fwd)
+            ub = bwd / nb if nb > 1e-8 else np.zeros_like(bwd)
+            spring = (ks[i] * uf - ks[i - 1] * ub).reshape(-1, 1)
+            F.append(-1 * (force + spring).reshape(-1, 3))
+        return np.array(F, dtype=float)
+
+
+class DNEB:
+    """CaluculationDNEB (pathopt_dneb_force.py:20-130), including its quirks."""
+
+    def __init__(self, APPLY_CI_NEB=99999):
+        self.k = 0.01
+        self.APPLY_CI_NEB = APPLY_CI_NEB
+        self.k_ci = 0.01
+
+    @staticmethod
+    def _unit(v):
+        n = np.linalg.norm(v)
+        return v / n if n != 0 else np.zeros_like(v)
+
+    def calc_force(self, X, E, G, optimize_num, element_list=None):
+        X = np.asarray(X, dtype=float)
+        G = np.asarray(G, dtype=float)
+        I, N = X.shape[0], X.shape[1]
+        maxlist, _ = extremum_list_index(E)
+        out = [-1 * G[0]]
+        for i in range(1, I - 1):
+            dmax = max(E[i + 1] - E[i], E[i - 1] - E[i])
+            dmin = min(E[i + 1] - E[i], E[i - 1] - E[i])
+            tau = np.zeros((N, 3))
+            if E[i - 1] < E[i] and E[i] < E[i + 1]:
+                for t in range(N):
+                    tau[t] = self._unit(X[i + 1][t] - X[i][t])
+            elif E[i - 1] > E[i] and E[i] > E[i + 1]:
+                for t in range(N):
+                    tau[t] = self._unit(X[i][t] - X[i - 1][t])
+            else:
+                for t in range(N):
+                    tm = self._unit(X[i][t] - X[i - 1][t])
+                    tp = self._unit(X[i + 1][t] - X[i][t])
+                    if E[i - 1] > E[i + 1]:
+                        v = tp * dmin + tm * dmax
+                        # where = np.linalg.norm(v != 0): true when any component is non-zero
+                        tau[t] = v / np.linalg.norm(v) if np.any(v != 0) else np.zeros(3)
+                    else:
+                        v = tp * dmax + tm * dmin
+                        nn = np.linalg.norm(tp * dmin + tm * dmax)      # the OTHER combination normalises
+                        tau[t] = v / nn if nn != 0 else np.zeros(3)
+            if E[i] == E[maxlist[0]] and self.APPLY_CI_NEB < optimize_num:
+                total = np.array([-self.k_ci * (G[i][f] - 2.0 * np.dot(G[i][f], tau[f]) * tau[f]) for f in range(N)])
+                del maxlist[0]
+            else:
+                total = np.zeros((N, 3))
+                for f in range(N):
+                    c = self.k * np.linalg.norm(X[i + 1][f] - X[i][f]) + (-1.0) * self.k * np.linalg.norm(X[i][f] - X[i - 1][f])
+                    fpar = c * tau[f]
+                    fperp = G[i][f] - np.dot(G[i][f], tau[f]) * tau[f]
+                    w = c - (c * tau[f]) * tau[f]
+                    nw = np.linalg.norm(w)
+                    ratio = np.ones(3) if nw != 0 else np.zeros(3)
+                    sw = (2.0 / np.pi) * np.arctan(ratio) * (w - np.dot(w, fperp) * fperp)
+                    total[f] = -fperp - fpar - sw
+            mm = np.nanmean(np.nanmean(total))
+            if mm > 10:
+                total = total / mm
+            out.append(total)
+        out.append(-1 * G[-1])
+        return np.array(out, dtype=float)

@@ -285,6 +285,35 @@ def g4_brentq():
     print("G4 done, scipy", scipy.__version__)
 
 
+def g6b_neb_variants():
+    """G6b: the spring/tangent variants named in the north star: DNEB, EWBNEB, BNEB3 calc_force."""
+    from multioptpy.MEP import pathopt_bneb_force as bf
+    from multioptpy.MEP import pathopt_dneb_force as df
+    from multioptpy.MEP import pathopt_ewbneb_force as ef
+    out = {}
+    k = 0
+    bumps = (None, [0, 1e-3, 2e-3, 1.5e-3, 1e-3, 1.2e-3, 2.5e-3, 0.5e-3], [0, -1e-3, -2e-3, -3e-3, -2e-3, -1e-3, 0, 1e-3],
+             [2e-3, 1e-3, 3e-3, 3e-3, 1e-3, 0.5e-3, 0.7e-3, 0.0])
+    for N in (7, 14):
+        for bump in bumps:
+            for ci in (False, True):
+                X, E, G = _band_inputs(8, N, bump)
+                if k % 3 == 1:
+                    X[3, 2] = X[2, 2]
+                tag = f"v{k:02d}"
+                out[tag + "_X"], out[tag + "_E"], out[tag + "_G"] = X, E, G
+                out[tag + "_ci"] = np.array(int(ci))
+                apply = 2 if ci else 99999
+                with quiet():
+                    out[tag + "_dneb"] = df.CaluculationDNEB(apply).calc_force(X.copy(), E.copy(), G.copy(), 5, ["Ar"] * N)
+                    out[tag + "_ewbneb"] = ef.CaluculationEWBNEB(apply).calc_force(X.copy(), E.copy(), G.copy(), 5, ["Ar"] * N)
+                    out[tag + "_bneb3"] = bf.CaluculationBNEB3(apply).calc_force(X.copy(), E.copy(), G.copy(), 5, ["Ar"] * N)
+                k += 1
+    out["ncase"] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, "g6b_neb_variants.npz"), **out)
+    print("G6b:", k, "cases")
+
+
 class _Cfg:
     pass
 
@@ -356,7 +385,7 @@ def g7_neb_step():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g6b", "g7"]
     if "g1" in which:
         g1_updates()
     if "g2" in which:
@@ -367,5 +396,7 @@ if __name__ == "__main__":
         g5_projections()
     if "g6" in which:
         g6_neb_forces()
+    if "g6b" in which:
+        g6b_neb_variants()
     if "g7" in which:
         g7_neb_step()

@@ -297,3 +297,19 @@ def test_band_warm_start_matches_cold():
     _os.environ.pop("MOPT_EIGH_WARM", None)
     assert np.abs(res["1"][0] - res["0"][0]).max() < 1e-9
     print("sweeps warm", res["1"][1], "cold", res["0"][1])
+
+
+def test_neb_spring_variants_vs_reference(ops):
+    """G6b: DNEB, EWBNEB, BNEB3 calc_force (incl. CI-NEB switches and DNEB's quirks) against the reference."""
+    z = np.load(os.path.join(G, "g6b_neb_variants.npz"))
+    from multioptpy_amd.MEP.pathopt_dneb_force import CaluculationDNEB
+    from multioptpy_amd.MEP.pathopt_ewbneb_force import CaluculationEWBNEB
+    from multioptpy_amd.MEP.pathopt_bneb_force import CaluculationBNEB3
+    for k in range(int(z["ncase"])):
+        tag = f"v{k:02d}"
+        X, E, Gr = z[tag + "_X"], z[tag + "_E"], z[tag + "_G"]
+        apply = 2 if int(z[tag + "_ci"]) else 99999
+        for cls, key in ((CaluculationDNEB, "dneb"), (CaluculationEWBNEB, "ewbneb"), (CaluculationBNEB3, "bneb3")):
+            F = cls(apply).calc_force(X, E, Gr, 5, ["Ar"] * X.shape[1])
+            err = np.abs(F - z[tag + "_" + key]).max()
+            assert err < 1e-12, (tag, key, err)

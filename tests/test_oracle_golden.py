@@ -169,3 +169,19 @@ def test_g7_rfo_neb_steps(variant):
         assert np.abs(np.array(opt.hessians) - z[tag + "_hess"]).max() < 1e-9
         assert np.allclose([o.trust_radius for o in opt.opts], z[tag + "_tr"], atol=1e-12)
         preX, preG, pre_vel = X.copy(), Gr.copy(), F.copy()
+
+
+@pytest.mark.parametrize("literal", [False, True])
+def test_g6b_neb_variants(literal):
+    z = np.load(os.path.join(G, "g6b_neb_variants.npz"))
+    for k in range(int(z["ncase"])):
+        tag = f"v{k:02d}"
+        X, E, Gr = z[tag + "_X"], z[tag + "_E"], z[tag + "_G"]
+        apply = 2 if int(z[tag + "_ci"]) else 99999
+        F = oneb.BNEB3(apply, literal=literal).calc_force(X, E, Gr, 5)
+        assert np.abs(F - z[tag + "_bneb3"]).max() < 1e-12, (tag, "bneb3")
+        F = oneb.EWBNEB(apply, literal=literal).calc_force(X, E, Gr, 5)
+        assert np.abs(F - z[tag + "_ewbneb"]).max() < 1e-12, (tag, "ewbneb")
+        if not literal:
+            F = oneb.DNEB(apply).calc_force(X, E, Gr, 5)
+            assert np.abs(F - z[tag + "_dneb"]).max() < 1e-12, (tag, "dneb", np.abs(F - z[tag + "_dneb"]).max())
