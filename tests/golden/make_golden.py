@@ -255,6 +255,48 @@ def g6_neb_forces():
     print("G6:", k, "cases")
 
 
+def g3_rsprfo():
+    """G3: consecutive EnhancedRSPRFO.run calls (P-RFO TS search and saddle_order 0), with the Hessian re-set every
+    step from the caller's array (optmain with -fc -1: the update is discarded) or set once."""
+    from multioptpy.Optimizer import rsprfo
+    out = {}
+    cfgs = [("rsprfo_bofill", 1, 7, 5, "once", 0), ("rsprfo_bofill", 1, 11, 5, "every", 1), ("rsprfo_bfgs", 0, 7, 4, "once", 2),
+            ("rsprfo_fsb", 1, 22, 4, "once", 3), ("rsprfo_block_bofill", 2, 11, 4, "once", 4), ("rsprfo_bofill", 1, 14, 6, "once", 5)]
+    for ci, (method, so, N, nsteps, mode, seed) in enumerate(cfgs):
+        tag = f"p{ci:02d}"
+        x = cases.cluster(N, seed_offset=seed)
+        n = 3 * N
+        H0 = cases.lj(x, hessian=True)[2]
+        opt = rsprfo.EnhancedRSPRFO(method=method, saddle_order=so, trust_radius_max=0.3 if so > 0 else 0.5, trust_radius_min=0.01)
+        out[tag + "_meta"] = np.array([N, so, nsteps, seed])
+        out[tag + "_method"] = np.array(method)
+        out[tag + "_mode"] = np.array(mode)
+        px = pg = pE = pmove = None
+        for k in range(nsteps):
+            E, G = cases.lj(x)
+            g = G.reshape(-1, 1)
+            xx = x.reshape(-1, 1).copy()
+            if mode == "every" or k == 0:
+                opt.set_hessian(H0)
+                opt.set_bias_hessian(np.zeros((n, n)))
+            with quiet():
+                if k == 0:
+                    step = opt.run(xx, g, [], [], E, 0.0, [], [], g, [])
+                else:
+                    step = opt.run(xx, g, pg, px, E, pE, pmove, [], g, pg)
+            out[f"{tag}_s{k}_x"], out[f"{tag}_s{k}_g"], out[f"{tag}_s{k}_E"] = xx.copy(), g.copy(), np.array(E)
+            out[f"{tag}_s{k}_step"] = np.asarray(step).copy()
+            out[f"{tag}_s{k}_tr"] = np.array(opt.trust_radius)
+            out[f"{tag}_s{k}_pred"] = np.array(opt.predicted_energy_changes[-1])
+            out[f"{tag}_s{k}_H"] = np.array(opt.hessian).copy()
+            out[f"{tag}_s{k}_tsidx"] = np.array(-1 if opt.ts_mode_idx is None else int(opt.ts_mode_idx))
+            px, pg, pE, pmove = xx, g, E, np.asarray(step).copy()
+            x = (xx - step).reshape(-1, 3)
+    out["ncfg"] = np.array(len(cfgs))
+    np.savez_compressed(os.path.join(HERE, "g3_rsprfo.npz"), **out)
+    print("G3:", len(cfgs), "traces")
+
+
 BRENT_FUNCS = {
     "cubic": (lambda t: t ** 3 - 2 * t - 5, 2.0, 3.0),
     "cosx": (lambda t: np.cos(t) - t, 0.0, 1.0),
@@ -385,11 +427,13 @@ def g7_neb_step():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g4", "g5", "g6", "g6b", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7"]
     if "g1" in which:
         g1_updates()
     if "g2" in which:
         g2_rsirfo()
+    if "g3" in which:
+        g3_rsprfo()
     if "g4" in which:
         g4_brentq()
     if "g5" in which:

@@ -185,3 +185,40 @@ def test_g6b_neb_variants(literal):
         if not literal:
             F = oneb.DNEB(apply).calc_force(X, E, Gr, 5)
             assert np.abs(F - z[tag + "_dneb"]).max() < 1e-12, (tag, "dneb", np.abs(F - z[tag + "_dneb"]).max())
+
+
+def _replay_rsprfo(z, tag, cls):
+    N, so, nsteps, seed = [int(v) for v in z[tag + "_meta"]]
+    method, mode = str(z[tag + "_method"]), str(z[tag + "_mode"])
+    n = 3 * N
+    H0 = cases.lj(cases.cluster(N, seed_offset=seed), hessian=True)[2]
+    opt = cls(method=method, saddle_order=so, trust_radius_max=0.3 if so > 0 else 0.5, trust_radius_min=0.01)
+    px = pg = pE = pmove = None
+    for k in range(nsteps):
+        x, g, E = z[f"{tag}_s{k}_x"], z[f"{tag}_s{k}_g"], float(z[f"{tag}_s{k}_E"])
+        if mode == "every" or k == 0:
+            opt.set_hessian(H0)
+            opt.set_bias_hessian(np.zeros((n, n)))
+        if k == 0:
+            step = opt.run(x, g, [], [], E, 0.0, [], [], g, [])
+        else:
+            step = opt.run(x, g, pg, px, E, pE, pmove, [], g, pg)
+        yield k, opt, step
+        px, pg, pE, pmove = x, g, E, z[f"{tag}_s{k}_step"]
+
+
+def test_g3_rsprfo_traces():
+    from oracle.rsprfo import EnhancedRSPRFO
+    z = np.load(os.path.join(G, "g3_rsprfo.npz"))
+    for i in range(int(z["ncfg"])):
+        tag = f"p{i:02d}"
+        for k, opt, step in _replay_rsprfo(z, tag, EnhancedRSPRFO):
+            ref = z[f"{tag}_s{k}_step"]
+            assert np.abs(step - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), (tag, k, np.abs(step - ref).max())
+            assert abs(opt.trust_radius - float(z[f"{tag}_s{k}_tr"])) < 1e-12, (tag, k)
+            pr = float(z[f"{tag}_s{k}_pred"])
+            assert abs(opt.predicted_energy_changes[-1] - pr) < 1e-9 * max(1.0, abs(pr)), (tag, k)
+            assert np.abs(opt.hessian - z[f"{tag}_s{k}_H"]).max() < 1e-9, (tag, k)
+            ts = int(z[f"{tag}_s{k}_tsidx"])
+            if opt.saddle_order == 1:      # order 2: both shifted modes sit at -0.001, the tracked index is gauge dependent
+                assert (opt.ts_mode_idx is None and ts == -1) or int(opt.ts_mode_idx) == ts, (tag, k)
