@@ -152,6 +152,57 @@ int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *p
                     const double *geom, const double *B_g, const double *g, const double *pre_geom,
                     const double *pre_g, const double *B_e, double *step, double *H_inplace, double *H_sym);
 
+/* ---- EnhancedRSPRFO.run (multioptpy/Optimizer/rsprfo.py:713-886): P-RFO transition-state step ------------------ */
+
+typedef struct mopt_rsprfo_params {
+    /* constructor configuration, rsprfo.py:84-190 */
+    double alpha0, alpha_max, alpha_min, alpha_step_max;
+    double micro_cycle_rtol, micro_cycle_atol;
+    double trust_radius_min, trust_radius_max;
+    double eta_2, eta_3, gamma_1, gamma_2;
+    double rejection_threshold;
+    double min_positive_eigval, min_negative_eigval;
+    double gradient_scaling_threshold, min_step_scale, gradient_trust_coupling;
+    double overlap_threshold, mixing_threshold;
+    int32_t max_micro_cycles, saddle_order, rule;
+    int32_t step_rejection_enabled, max_consecutive_rejections;
+    int32_t hessian_shift_enabled, gradient_scaling_enabled, adaptive_trust_enabled, adapt_trust_radius;
+    int32_t mode_following_enabled, eigvec_following;
+    int32_t reserved;
+} mopt_rsprfo_params;
+
+typedef struct mopt_rsprfo_state {
+    double trust_radius;
+    double prev_energy;
+    double last_predicted;          /* predicted_energy_changes[-1] */
+    double last_ratio;              /* out: reduction ratio of the processed previous step (NaN if none) */
+    double last_actual;             /* out: actual energy change appended this call (NaN if none) */
+    double new_predicted;           /* out: predicted energy change of this step */
+    int32_t has_prev;               /* prev_energy is not None and predictions exist */
+    int32_t consecutive_rejections;
+    int32_t ts_mode_idx;            /* -1 = None */
+    int32_t iter;
+    /* diagnostics */
+    int32_t hess_updated, shifted, step_accepted, micro_converged, n_max, jacobi_sweeps;
+    double step_norm, gradient_norm;
+} mopt_rsprfo_state;
+
+/* One EnhancedRSPRFO.run for a single geometry (n = 3N).
+ *   hessian       in : n x n (self.hessian, already symmetrised by set_hessian), bias_hessian n x n or NULL
+ *   geom, B_g     in : n          current geometry / gradient
+ *   pre_geom, pre_B_g in: n or NULL   (Hessian update with B_g - pre_B_g, rsprfo.py:763-765)
+ *   prev_gradient, prev_move_vector in: n or NULL  (self.prev_gradient / self.prev_move_vector of the previous call)
+ *   pre_move_norm in : |pre_move_vector| handed in by the caller, < 0 when the argument was empty (rsprfo.py:924-929)
+ *   ts_vec        in : n or NULL  tracked TS eigenvector (self.ts_mode_eigvec)
+ *   step         out : n          the returned move vector (to be subtracted by the caller)
+ *   H_out        out : n x n      self.hessian after the (possibly reverted) update
+ *   ts_vec_out   out : n          new tracked eigenvector (untouched when saddle_order == 0) */
+int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *params, mopt_rsprfo_state *state,
+                    const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
+                    const double *pre_geom, const double *pre_B_g, double B_e, const double *prev_gradient,
+                    const double *prev_move_vector, double pre_move_norm, const double *ts_vec, double *step,
+                    double *H_out, double *ts_vec_out);
+
 /* ---- NEB band ------------------------------------------------------------------------ */
 
 /* CaluculationBNEB.calc_force (multioptpy/MEP/pathopt_bneb_force.py:33-65) for I images of N atoms.

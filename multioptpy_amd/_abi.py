@@ -89,3 +89,33 @@ def default_params(**kw):
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+class RsprfoParams(C.Structure):
+    _fields_ = [
+        ("alpha0", C.c_double), ("alpha_max", C.c_double), ("alpha_min", C.c_double), ("alpha_step_max", C.c_double),
+        ("micro_cycle_rtol", C.c_double), ("micro_cycle_atol", C.c_double),
+        ("trust_radius_min", C.c_double), ("trust_radius_max", C.c_double),
+        ("eta_2", C.c_double), ("eta_3", C.c_double), ("gamma_1", C.c_double), ("gamma_2", C.c_double),
+        ("rejection_threshold", C.c_double),
+        ("min_positive_eigval", C.c_double), ("min_negative_eigval", C.c_double),
+        ("gradient_scaling_threshold", C.c_double), ("min_step_scale", C.c_double), ("gradient_trust_coupling", C.c_double),
+        ("overlap_threshold", C.c_double), ("mixing_threshold", C.c_double),
+        ("max_micro_cycles", C.c_int32), ("saddle_order", C.c_int32), ("rule", C.c_int32),
+        ("step_rejection_enabled", C.c_int32), ("max_consecutive_rejections", C.c_int32),
+        ("hessian_shift_enabled", C.c_int32), ("gradient_scaling_enabled", C.c_int32), ("adaptive_trust_enabled", C.c_int32),
+        ("adapt_trust_radius", C.c_int32),
+        ("mode_following_enabled", C.c_int32), ("eigvec_following", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class RsprfoState(C.Structure):
+    _fields_ = [
+        ("trust_radius", C.c_double), ("prev_energy", C.c_double), ("last_predicted", C.c_double),
+        ("last_ratio", C.c_double), ("last_actual", C.c_double), ("new_predicted", C.c_double),
+        ("has_prev", C.c_int32), ("consecutive_rejections", C.c_int32), ("ts_mode_idx", C.c_int32), ("iter", C.c_int32),
+        ("hess_updated", C.c_int32), ("shifted", C.c_int32), ("step_accepted", C.c_int32), ("micro_converged", C.c_int32),
+        ("n_max", C.c_int32), ("jacobi_sweeps", C.c_int32),
+        ("step_norm", C.c_double), ("gradient_norm", C.c_double),
+    ]

@@ -286,3 +286,10 @@ int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, 
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }
+
+int mopt_launch_norm_inf(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma) {
+    using namespace mopt;
+    hipLaunchKernelGGL(k_jac_sigma, dim3(batch), dim3(256), 0, ctx->stream, n, d_A, d_sigma);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}

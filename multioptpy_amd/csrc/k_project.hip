@@ -188,16 +188,21 @@ __global__ void __launch_bounds__(256) k_proj_apply(int n, double *__restrict__ 
 }
 
 // Householder QR (dgeqr2 conventions) of the n x kc matrix, applied to g.  dynamic LDS: 7 * n doubles.
-__global__ void __launch_bounds__(256) k_proj_grad(int n, const double *__restrict__ G, const double *__restrict__ X,
+__global__ void __launch_bounds__(256) k_proj_grad(int n, int variant, const double *__restrict__ G, const double *__restrict__ X,
                                                    double *__restrict__ GP) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[6 * 16];
     __shared__ double taus[6];
+    __shared__ double rdiag[6];
     double *Acol = sm;          // [6][n] column-major
     double *t = sm + 6 * n;     // [n]
     const int b = blockIdx.x;
     const double *x = X + (size_t)b * n;
     const double *g = G + (size_t)b * n;
+    if (variant == 1 && n < 9) {          // rsprfo.py:245-246: fewer than 3 atoms -> gradient returned unprojected
+        for (int i = threadIdx.x; i < n; i += blockDim.x) GP[(size_t)b * n + i] = g[i];
+        return;
+    }
     double cx, cy, cz;
     centre_of(n, x, red, cx, cy, cz);
     build_trrot(n, x, cx, cy, cz, Acol, n);
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(256) k_proj_grad(int n, const double *__restri
         } else {
             if (threadIdx.x == 0) col[j] = 1.0;
         }
-        if (threadIdx.x == 0) taus[j] = tau;
+        if (threadIdx.x == 0) { taus[j] = tau; rdiag[j] = (xnorm != 0.0) ? -copysign(hypot(alpha, xnorm), alpha) : alpha; }
         __syncthreads();
         if (tau != 0.0) {
             // apply H_j = I - tau v v^T to the trailing columns and to t
@@ -243,6 +248,7 @@ __global__ void __launch_bounds__(256) k_proj_grad(int n, const double *__restri
     }
     // t = [Q^T g ; rest] -> keep the first kc entries, then Q t' = H_0 ... H_{kc-1} [t'; 0]
     for (int i = kc + threadIdx.x; i < n; i += blockDim.x) t[i] = 0.0;
+    if (variant == 1 && threadIdx.x < kc && !(fabs(rdiag[threadIdx.x]) > 1e-10)) t[threadIdx.x] = 0.0;   // Q[:, valid_cols] (rsprfo.py:275-277)
     __syncthreads();
     for (int j = kc - 1; j >= 0; --j) {
         const double tau = taus[j];
@@ -275,10 +281,18 @@ int mopt_launch_project_hess(mopt_ctx *ctx, int n, int batch, const double *d_H,
     return MOPT_OK;
 }
 
-int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp) {
+int mopt_launch_sym_add(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, double *d_A) {
+    using namespace mopt;
+    const int T = (n + 31) / 32;
+    hipLaunchKernelGGL(k_sym_add, dim3(T * T, batch), dim3(256), 0, ctx->stream, n, d_H, d_Bias, d_A);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp, int variant) {
     using namespace mopt;
     mopt_scope sc(ctx, "project", 1);
-    hipLaunchKernelGGL(k_proj_grad, dim3(batch), dim3(256), (size_t)7 * n * sizeof(double), ctx->stream, n, d_g, d_X, d_gp);
+    hipLaunchKernelGGL(k_proj_grad, dim3(batch), dim3(256), (size_t)7 * n * sizeof(double), ctx->stream, n, variant, d_g, d_X, d_gp);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

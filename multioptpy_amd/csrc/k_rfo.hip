@@ -241,3 +241,17 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }
+
+int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out) {
+    using namespace mopt;
+    hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_vec, d_einfo, d_out);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+int mopt_launch_backtransform(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_coef, const int *d_einfo, double *d_out) {
+    using namespace mopt;
+    hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_coef, d_einfo, d_out);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}

@@ -46,7 +46,7 @@ __global__ void __launch_bounds__(256) k_matvec(int n, const double *__restrict_
 }
 
 // One workgroup per image.  rule[b] per image (band: end images and interior images differ).
-__global__ void __launch_bounds__(256) k_update_coef(int n, const int *__restrict__ rules, const int *__restrict__ do_update,
+__global__ void __launch_bounds__(256) k_update_coef(int n, int guard_sy, const int *__restrict__ rules, const int *__restrict__ do_update,
                                                      const double *__restrict__ s_, const double *__restrict__ y_,
                                                      const double *__restrict__ u_, const double *__restrict__ Hy_,
                                                      double *__restrict__ yd_, double *__restrict__ A_,
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) k_update_coef(int n, const int *__restric
     block_sum<5>(w, red);
     d.syd = w[0]; d.AA = w[1]; d.As = w[2]; d.zz = w[3]; d.zs = w[4];
     if (threadIdx.x == 0) {
-        UpdateCoef c = update_coefficients(rule, d);
+        UpdateCoef c = update_coefficients(rule, d, guard_sy != 0);
         coef[b] = c;
         if (info) {
             double *o = info + (size_t)b * 8;
@@ -184,7 +184,7 @@ int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules,
                             const double *d_x, const double *d_px, const double *d_g, const double *d_pg,
                             double *d_s, double *d_y, double *d_u, double *d_Hy, double *d_yd, double *d_A,
                             mopt::UpdateCoef *d_coef, double *d_info, const double *d_H, double *d_Hinpl, double *d_Hsym,
-                            bool have_sy) {
+                            bool have_sy, bool guard_sy) {
     using namespace mopt;
     mopt_scope sc(ctx, "hess_update", 4);
     if (!have_sy) {
@@ -196,11 +196,18 @@ int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules,
         hipLaunchKernelGGL(k_matvec<2>, gm, dim3(256), 0, ctx->stream, n, d_H, d_s, d_y, d_u, d_Hy);
     else
         hipLaunchKernelGGL(k_matvec<1>, gm, dim3(256), 0, ctx->stream, n, d_H, d_s, (const double *)nullptr, d_u, (double *)nullptr);
-    hipLaunchKernelGGL(k_update_coef, dim3(batch), dim3(256), 0, ctx->stream, n, d_rules, d_do_update, d_s, d_y, d_u,
+    hipLaunchKernelGGL(k_update_coef, dim3(batch), dim3(256), 0, ctx->stream, n, guard_sy ? 1 : 0, d_rules, d_do_update, d_s, d_y, d_u,
                        any_flowchart ? d_Hy : (const double *)nullptr, d_yd, d_A, d_coef, d_info);
     const int T = (n + 31) / 32;
     hipLaunchKernelGGL(k_apply_update, dim3(T * T, batch), dim3(256), 0, ctx->stream, n, d_H, d_Hinpl, d_Hsym, d_coef,
                        d_yd, d_u, d_A, d_s);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+int mopt_launch_matvec(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_v, double *d_out) {
+    using namespace mopt;
+    hipLaunchKernelGGL(k_matvec<1>, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_H, d_v, (const double *)nullptr, d_out, (double *)nullptr);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

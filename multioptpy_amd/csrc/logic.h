@@ -139,13 +139,13 @@ MOPT_HD inline double blk_weight(const UpdateDots &d, double k, bool bofill_logi
 }
 
 // Coefficients for one (s, y) pair.  `d` must hold the dots computed with the (possibly damped) y'.
-MOPT_HD inline UpdateCoef update_coefficients(int rule, const UpdateDots &d) {
+MOPT_HD inline UpdateCoef update_coefficients(int rule, const UpdateDots &d, bool require_positive_sy = true) {
     UpdateCoef r;
     r.c_yy = r.c_uu = r.c_AA = r.c_As = r.c_ss = 0.0;
     r.applied = 0; r.block_sym = rule_is_block(rule) ? 1 : 0; r.mix = 0.0; r.branch = 0;
     // RSIRFO.update_hessian guards (rsirfo.py:1322-1335), on the ORIGINAL y
     if (sqrt(d.ss) < 1e-10 || sqrt(d.yy) < 1e-10) return r;
-    if (d.sy <= 0.0) return r;
+    if (require_positive_sy && d.sy <= 0.0) return r;      // EnhancedRSPRFO.update_hessian has no such guard (rsprfo.py:1205-1209)
     r.applied = 1;
     Acc5 a = zero5();
     switch (rule) {

@@ -39,10 +39,14 @@ int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules,
                             const double *d_x, const double *d_px, const double *d_g, const double *d_pg,
                             double *d_s, double *d_y, double *d_u, double *d_Hy, double *d_yd, double *d_A,
                             mopt::UpdateCoef *d_coef, double *d_info, const double *d_H, double *d_Hinpl, double *d_Hsym,
-                            bool have_sy);
+                            bool have_sy, bool guard_sy = true);
 int mopt_launch_project_hess(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, const double *d_X,
                              double *d_Q, double *d_W, double *d_A);
-int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp);
+// variant 0: RSIRFO._project_grad_tr_rot; 1: EnhancedRSPRFO._project_grad_tr_rot (no projection below 3 atoms, QR columns
+// with |R_jj| <= 1e-10 dropped)
+int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp, int variant = 0);
+int mopt_launch_matvec(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_v, double *d_out);
+int mopt_launch_sym_add(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, double *d_A);
 int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
                      int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps, bool warm);
@@ -54,5 +58,8 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
                     double *d_coefout, double *d_step);
 int mopt_launch_neb_force_var(mopt_ctx *ctx, int variant, int I, int N, int first, int count, const double *d_X, const double *d_E,
                               const double *d_G, int ci_active, double *d_F);
+int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out);
+int mopt_launch_backtransform(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_coef, const int *d_einfo, double *d_out);
+int mopt_launch_norm_inf(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma);   // sigma = 1.0625 * ||A||_inf
 int mopt_launch_bneb_force(mopt_ctx *ctx, int I, int N, int first, int count, const double *d_X, const double *d_E,
                            const double *d_G, int ci_active, double *d_F, double *d_tau);

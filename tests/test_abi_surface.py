@@ -38,6 +38,15 @@ def test_struct_layout_matches_header(tmp_path):
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     a, b, c, d = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    src2 = tmp_path / "sz2.c"
+    src2.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mopt_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", '
+                    'sizeof(mopt_rsprfo_params), sizeof(mopt_rsprfo_state), offsetof(mopt_rsprfo_params, max_micro_cycles), '
+                    'offsetof(mopt_rsprfo_state, step_norm));return 0;}\n')
+    exe2 = tmp_path / "sz2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src2), "-o", str(exe2)])
+    a2, b2, c2, d2 = [int(v) for v in subprocess.check_output([str(exe2)]).split()]
+    assert a2 == C.sizeof(_abi.RsprfoParams) and b2 == C.sizeof(_abi.RsprfoState)
+    assert c2 == _abi.RsprfoParams.max_micro_cycles.offset and d2 == _abi.RsprfoState.step_norm.offset
     assert a == C.sizeof(_abi.RsirfoParams)
     assert b == C.sizeof(_abi.RsirfoState)
     assert c == _abi.RsirfoParams.max_micro_cycles.offset

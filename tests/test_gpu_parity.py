@@ -313,3 +313,27 @@ def test_neb_spring_variants_vs_reference(ops):
             F = cls(apply).calc_force(X, E, Gr, 5, ["Ar"] * X.shape[1])
             err = np.abs(F - z[tag + "_" + key]).max()
             assert err < 1e-12, (tag, key, err)
+
+
+def test_rsprfo_traces_vs_reference():
+    """G3: EnhancedRSPRFO (P-RFO) consecutive run() calls against the reference: step, trust radius, predicted energy
+    change, self.hessian after the (checked) update, tracked TS mode index."""
+    from multioptpy_amd.Optimizer.rsprfo import EnhancedRSPRFO
+    import test_oracle_golden as tog
+    z = np.load(os.path.join(G, "g3_rsprfo.npz"))
+    worst = 0.0
+    for i in range(int(z["ncfg"])):
+        tag = f"p{i:02d}"
+        for k, opt, step in tog._replay_rsprfo(z, tag, EnhancedRSPRFO):
+            ref = z[f"{tag}_s{k}_step"]
+            err = np.abs(step - ref).max()
+            worst = max(worst, err)
+            assert err < 1e-8 * max(1.0, np.abs(ref).max()), (tag, k, err)
+            assert abs(opt.trust_radius - float(z[f"{tag}_s{k}_tr"])) < 1e-12, (tag, k)
+            pr = float(z[f"{tag}_s{k}_pred"])
+            assert abs(opt.predicted_energy_changes[-1] - pr) < 1e-8 * max(1.0, abs(pr)), (tag, k)
+            assert np.abs(opt.hessian - z[f"{tag}_s{k}_H"]).max() < 1e-8, (tag, k)
+            ts = int(z[f"{tag}_s{k}_tsidx"])
+            if opt.saddle_order == 1:
+                assert (opt.ts_mode_idx is None and ts == -1) or int(opt.ts_mode_idx) == ts, (tag, k)
+    print("RSPRFO worst step deviation from the reference:", worst)
