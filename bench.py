@@ -175,7 +175,8 @@ def main():
     b2 = Band(I, N, first=first, count=count, device=local)
     run(b2, timing=(rank == 0))
     if rank == 0:
-        for name in ("hess_update", "project", "eigh_init", "eigh_jacobi", "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post"):
+        for name in ("hess_update", "project", "eigh_init", "eigh_jacobi", "eigh_tridiag", "eigh_bisect", "eigh_invit", "eigh_backtrans",
+                     "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post"):
             ms, nl = b2.timing_read(name)
             fam[name] = {"ms_per_step": ms / K, "launches_per_step": nl / K}
         b2.timing(False)

@@ -1,0 +1,471 @@
+// Batched symmetric eigen-solver, reduction route (LAPACK dsytrd / dstebz / dstein / dormtr restated for gfx950):
+//   k_tridiag        Householder tridiagonalisation A = Q T Q^T, one workgroup per matrix, the trailing matrix streamed from
+//                    L2 (n = 300: 720 KB), reflectors kept in the rows of A
+//   k_tri_bisect     splitting at negligible off-diagonals, Sturm-count bisection, one thread per eigenvalue; cluster table
+//   k_tri_invit      inverse iteration per eigenvalue (dlagtf / dlagts pivoted tridiagonal LU), one wave per cluster with
+//                    modified Gram-Schmidt inside a cluster (eigenvalues closer than 1e-3 ||T||)
+//   k_tri_backtrans  V = Q Z: the n-2 reflectors applied to 16 eigenvectors per workgroup, reflector staged through LDS
+// ~ (4/3 + 2) n^3 flops instead of the ~70 n^3 of the Jacobi route (k_eigh.hip); same output contract:
+// W ascending, perm, Vt vector-major, einfo.
+#include <cstdlib>
+#include "pipeline.h"
+
+namespace mopt {
+
+constexpr double DEPS = 2.220446049250313e-16;
+constexpr double DTINY = 2.2250738585072014e-308;
+
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_tridiag(int n, int dbg, double *__restrict__ A_, double *__restrict__ D_, double *__restrict__ E_,
+                                                  double *__restrict__ TAU_) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[2 * 16];
+    double *sv = sm, *sp = sm + n, *sw = sm + 2 * n, *spart = sm + 3 * n;
+    const int b = blockIdx.x;
+    double *A = A_ + (size_t)b * n * n;
+    double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nw = blockDim.x >> 6;
+    for (int k = 0; k < n - 2; ++k) {
+        const int m = n - k - 1;
+        double *rowk = A + (size_t)k * n + (k + 1);      // x = A[k][k+1 .. n-1]  (== column k below the diagonal)
+        double part = 0.0;
+        for (int j = 1 + tid; j < m; j += blockDim.x) { const double x = rowk[j]; part += x * x; }
+        const double xn2 = block_sum1(part, red);
+        const double alpha = rowk[0];
+        const double xnorm = sqrt(xn2);
+        double tau = 0.0, beta = alpha, scal = 0.0;
+        if (xnorm != 0.0) {
+            beta = -copysign(hypot(alpha, xnorm), alpha);
+            tau = (beta - alpha) / beta;
+            scal = 1.0 / (alpha - beta);
+        }
+        __syncthreads();                                   // everybody has read alpha before row k is overwritten
+        for (int j = tid; j < m; j += blockDim.x) {
+            const double vj = (j == 0) ? 1.0 : rowk[j] * scal;
+            sv[j] = vj;
+            if (j > 0) rowk[j] = vj;                       // reflector kept in row k (v[0] = 1 implicit)
+        }
+        __syncthreads();
+        if (tau != 0.0) {
+            // p = tau * A22 v.  A22 is symmetric: thread (column j, row part r) sums A[i][j] v_i over rows i = r (mod P) --
+            // every load is a coalesced row segment and no cross-lane reduction is needed; the P parts meet in LDS.
+            // CW = columns rounded up to whole waves, P = 1024 / CW row parts; 4 independent loads in flight per thread.
+            const int CW = ((m + 63) >> 6) << 6;
+            const int P = (int)blockDim.x / CW;
+            const int tj = tid % CW, tr = tid / CW;
+            const double *A22 = A + (size_t)(k + 1) * n + (k + 1);
+            if (!(dbg & 1) && tr < P && tj < m) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                int i = tr;
+                for (; i + 3 * P < m; i += 4 * P) {
+                    const double x0 = A22[(size_t)i * n + tj], x1 = A22[(size_t)(i + P) * n + tj];
+                    const double x2 = A22[(size_t)(i + 2 * P) * n + tj], x3 = A22[(size_t)(i + 3 * P) * n + tj];
+                    a0 += x0 * sv[i]; a1 += x1 * sv[i + P]; a2 += x2 * sv[i + 2 * P]; a3 += x3 * sv[i + 3 * P];
+                }
+                for (; i < m; i += P) a0 += A22[(size_t)i * n + tj] * sv[i];
+                spart[tr * n + tj] = (a0 + a1) + (a2 + a3);
+            }
+            __syncthreads();
+            double pv = 0.0;
+            for (int j = tid; j < m; j += blockDim.x) {
+                double acc = 0.0;
+                for (int r = 0; r < P; ++r) acc += spart[r * n + j];
+                const double pj = tau * acc;
+                sp[j] = pj;
+                pv += pj * sv[j];
+            }
+            pv = block_sum1(pv, red);
+            const double c = -0.5 * tau * pv;
+            for (int j = tid; j < m; j += blockDim.x) sw[j] = sp[j] + c * sv[j];
+            __syncthreads();
+            // A22 -= v w^T + w v^T   (same thread layout)
+            double *B22 = A + (size_t)(k + 1) * n + (k + 1);
+            if (!(dbg & 2) && tr < P && tj < m) {
+                const double wj = sw[tj], vj = sv[tj];
+                int i = tr;
+                for (; i + 3 * P < m; i += 4 * P) {
+                    double *q0 = B22 + (size_t)i * n + tj, *q1 = B22 + (size_t)(i + P) * n + tj;
+                    double *q2 = B22 + (size_t)(i + 2 * P) * n + tj, *q3 = B22 + (size_t)(i + 3 * P) * n + tj;
+                    const double x0 = *q0, x1 = *q1, x2 = *q2, x3 = *q3;
+                    *q0 = x0 - (sv[i] * wj + sw[i] * vj);
+                    *q1 = x1 - (sv[i + P] * wj + sw[i + P] * vj);
+                    *q2 = x2 - (sv[i + 2 * P] * wj + sw[i + 2 * P] * vj);
+                    *q3 = x3 - (sv[i + 3 * P] * wj + sw[i + 3 * P] * vj);
+                }
+                for (; i < m; i += P) B22[(size_t)i * n + tj] -= sv[i] * wj + sw[i] * vj;
+            }
+        }
+        if (tid == 0) { D[k] = A[(size_t)k * n + k]; E[k] = beta; TAU[k] = tau; }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (n >= 2) {
+            D[n - 2] = A[(size_t)(n - 2) * n + (n - 2)];
+            E[n - 2] = A[(size_t)(n - 2) * n + (n - 1)];
+            TAU[n - 2] = 0.0;
+        }
+        D[n - 1] = A[(size_t)(n - 1) * n + (n - 1)];
+        E[n - 1] = 0.0; TAU[n - 1] = 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// number of eigenvalues of the block (d[s..t), off-diagonals e2 = e^2) that are < x
+__device__ __forceinline__ int sturm_count(const double *d, const double *e2, int s, int t, double x, double pivmin) {
+    int cnt = 0;
+    double q = d[s] - x;
+    if (fabs(q) < pivmin) q = -pivmin;
+    cnt += (q < 0.0);
+    for (int i = s + 1; i < t; ++i) {
+        q = d[i] - x - e2[i - 1] / q;
+        if (fabs(q) < pivmin) q = -pivmin;
+        cnt += (q < 0.0);
+    }
+    return cnt;
+}
+
+// One workgroup per matrix.  Outputs: WT[n] eigenvalues (block by block, ascending inside a block), bstart[n]/bend[n] block
+// range of every index, cstart[] cluster start list (ncl[b] clusters), E zeroed at the split points, onenrm per index.
+// dynamic LDS: 3 n doubles + 2 n ints
+__global__ void __launch_bounds__(256) k_tri_bisect(int n, const double *__restrict__ D_, double *__restrict__ E_, double *__restrict__ WT_,
+                                                    int *__restrict__ bstart_, int *__restrict__ bend_, int *__restrict__ cstart_,
+                                                    int *__restrict__ ncl_, double *__restrict__ onenrm_) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *d = sm, *e = sm + n, *e2 = sm + 2 * n;
+    int *bs = (int *)(sm + 3 * n), *be = bs + n;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *D = D_ + (size_t)b * n;
+    double *E = E_ + (size_t)b * n, *WT = WT_ + (size_t)b * n, *onenrm = onenrm_ + (size_t)b * n;
+    int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n, *cstart = cstart_ + (size_t)b * n;
+    for (int i = tid; i < n; i += blockDim.x) { d[i] = D[i]; e[i] = (i < n - 1) ? E[i] : 0.0; }
+    __syncthreads();
+    // splitting.  dstebz drops e_i when e_i^2 <= ulp^2 |d_i d_{i+1}|; the Hessians of this path are often identity + low rank
+    // (rfo_neb.py:25), whose reduced form carries off-diagonals of a few sqrt(n) ulp between hundreds of numerically equal
+    // diagonal entries -- left in place they form one giant cluster for the inverse iteration.  Dropping |e_i| <= 32 ulp
+    // (|d_i| + |d_{i+1}|) perturbs eigenvalues by at most that much (1.4e-14 relative to the local scale).
+    for (int i = tid; i < n; i += blockDim.x) {
+        if (i < n - 1) {
+            const double ei = e[i];
+            if (fabs(ei) <= 32.0 * DEPS * (fabs(d[i]) + fabs(d[i + 1])) || fabs(ei) < DTINY) { e2[i] = 0.0; }
+            else e2[i] = ei * ei;
+        } else e2[i] = 0.0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) { if (i < n - 1 && e2[i] == 0.0) e[i] = 0.0; E[i] = e[i]; }
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        int s = i; while (s > 0 && e2[s - 1] != 0.0) --s;
+        int t = i + 1; while (t < n && e2[t - 1] != 0.0) ++t;
+        bs[i] = s; be[i] = t; bstart[i] = s; bend[i] = t;
+    }
+    __syncthreads();
+    // eigenvalue j of its block by bisection
+    for (int j = tid; j < n; j += blockDim.x) {
+        const int s = bs[j], t = be[j], kk = j - s;
+        double nrm1 = 0.0;
+        if (t - s == 1) { WT[j] = d[s]; onenrm[j] = fabs(d[s]); continue; }
+        double gl = INFINITY, gu = -INFINITY, e2max = 0.0;
+        for (int i = s; i < t; ++i) {
+            const double lo_ = (i > s ? fabs(e[i - 1]) : 0.0), hi_ = (i < t - 1 ? fabs(e[i]) : 0.0);
+            gl = fmin(gl, d[i] - lo_ - hi_); gu = fmax(gu, d[i] + lo_ + hi_);
+            nrm1 = fmax(nrm1, fabs(d[i]) + lo_ + hi_);
+            if (i < t - 1) e2max = fmax(e2max, e2[i]);
+        }
+        const double pivmin = fmax(DTINY * fmax(1.0, e2max), DTINY);
+        const double bn = fmax(fabs(gl), fabs(gu));
+        gl -= 2.1 * bn * DEPS * (t - s) + 2.1 * pivmin; gu += 2.1 * bn * DEPS * (t - s) + 2.1 * pivmin;
+        double lo = gl, hi = gu;
+        for (int it = 0; it < 200; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (!(mid > lo && mid < hi)) break;
+            if (sturm_count(d, e2, s, t, mid, pivmin) > kk) hi = mid; else lo = mid;
+            if (hi - lo <= 2.0 * DEPS * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
+        }
+        WT[j] = 0.5 * (lo + hi);
+        onenrm[j] = nrm1;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // cluster table (dstein: a new cluster when lambda_j - lambda_{j-1} > 1e-3 * ||T_block||_1), serial compaction by one thread
+    if (tid == 0) {
+        int nc = 0;
+        for (int j = 0; j < n; ++j) {
+            const bool first = (j == bs[j]) || (fabs(WT[j] - WT[j - 1]) > 1e-3 * onenrm[j]);
+            if (first) cstart[nc++] = j;
+        }
+        ncl_[b] = nc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lcg_uniform(unsigned long long &s) {
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+    return ((double)(s >> 11) * (1.0 / 9007199254740992.0)) * 2.0 - 1.0;
+}
+
+// One wave (= one 64-thread workgroup, so that __syncthreads is a wave-level sync) per cluster, grid-stride over clusters.
+// Zt vector-major: row j = eigenvector j of T (zero outside its block).  LDS: 5 n doubles + n ints.
+__global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restrict__ D_, const double *__restrict__ E_,
+                                                        const double *__restrict__ WT_, const int *__restrict__ bstart_,
+                                                        const int *__restrict__ bend_, const int *__restrict__ cstart_,
+                                                        const int *__restrict__ ncl_, const double *__restrict__ onenrm_,
+                                                        double *__restrict__ Zt_, int *__restrict__ fail_) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int gw = blockIdx.x, ngw = gridDim.x;
+    double *base = sm;
+    double *a = base, *bb = a + n, *c = bb + n, *dd = c + n, *x = dd + n;
+    int *inn = (int *)(x + n);
+    const double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *WT = WT_ + (size_t)b * n, *onenrm = onenrm_ + (size_t)b * n;
+    const int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n, *cstart = cstart_ + (size_t)b * n;
+    double *Zt = Zt_ + (size_t)b * n * n;
+    const int nc = ncl_[b];
+    for (int ci = gw; ci < nc; ci += ngw) {
+        const int j0 = cstart[ci];
+        const int s = bstart[j0], t = bend[j0], m = t - s;
+        const int j1 = (ci + 1 < nc && cstart[ci + 1] < t) ? cstart[ci + 1] : t;      // cluster = eigenvalues [j0, j1) of block [s, t)
+        double xjm = 0.0;
+        for (int j = j0; j < j1; ++j) {
+            double *z = Zt + (size_t)j * n;
+            for (int i = lane; i < n; i += WAVE) z[i] = 0.0;
+            if (m == 1) { if (lane == 0) z[s] = 1.0; continue; }
+            const double nrm1 = onenrm[j];
+            double xj = WT[j];
+            if (j > j0) {                                   // dstein: separate (numerically) coincident eigenvalues of a cluster
+                const double pertol = 10.0 * fabs(DEPS * xj);
+                if (xj - xjm < pertol) xj = xjm + pertol;
+            }
+            // ---- dlagtf: T - xj I = P L U   (serial, lane 0; arrays in LDS)
+            if (lane == 0) {
+                for (int i = 0; i < m; ++i) { a[i] = D[s + i] - xj; if (i < m - 1) { bb[i] = E[s + i]; c[i] = E[s + i]; } }
+                double scale1 = fabs(a[0]) + fabs(bb[0]);
+                for (int k = 0; k < m - 1; ++k) {
+                    const double scale2 = fabs(c[k]) + fabs(a[k + 1]) + ((k < m - 2) ? fabs(bb[k + 1]) : 0.0);
+                    const double piv1 = (a[k] == 0.0) ? 0.0 : fabs(a[k]) / scale1;
+                    if (c[k] == 0.0) {
+                        inn[k] = 0; scale1 = scale2;
+                        if (k < m - 2) dd[k] = 0.0;
+                    } else {
+                        const double piv2 = fabs(c[k]) / scale2;
+                        if (piv2 <= piv1) {
+                            inn[k] = 0; scale1 = scale2;
+                            c[k] = c[k] / a[k]; a[k + 1] -= c[k] * bb[k];
+                            if (k < m - 2) dd[k] = 0.0;
+                        } else {
+                            inn[k] = 1;
+                            const double mult = a[k] / c[k];
+                            a[k] = c[k];
+                            const double temp = a[k + 1];
+                            a[k + 1] = bb[k] - mult * temp;
+                            if (k < m - 2) { dd[k] = bb[k + 1]; bb[k + 1] = -mult * dd[k]; }
+                            bb[k] = temp; c[k] = mult;
+                        }
+                    }
+                }
+            }
+            unsigned long long seed = 0x9E3779B97F4A7C15ULL ^ ((unsigned long long)(j + 1) << 20);     // independent of the batch slot: shard == whole
+            for (int i = lane; i < m; i += WAVE) { unsigned long long s2 = seed + 0x632BE59BD9B4E019ULL * (unsigned long long)(i + 1); lcg_uniform(s2); x[i] = lcg_uniform(s2); }
+            __syncthreads();
+            const double stpcrt = sqrt(0.1 / m);
+            const double tol = DEPS * nrm1;
+            int nrmchk = 0, its = 0;
+            bool ok = false;
+            while (its < 5) {
+                ++its;
+                double asum = 0.0;
+                for (int i = lane; i < m; i += WAVE) asum += fabs(x[i]);
+                asum = wave_sum(asum);
+                const double scl = m * nrm1 * fmax(DEPS, fabs(a[m - 1])) / asum;
+                for (int i = lane; i < m; i += WAVE) x[i] *= scl;
+                __syncthreads();
+                // ---- dlagts (job = -1): solve with perturbation of tiny pivots (serial, lane 0)
+                if (lane == 0) {
+                    for (int k = 1; k < m; ++k) {
+                        if (inn[k - 1] == 0) x[k] -= c[k - 1] * x[k - 1];
+                        else { const double tmp = x[k - 1]; x[k - 1] = x[k]; x[k] = tmp - c[k - 1] * x[k]; }
+                    }
+                    const double bignum = 1.0 / DTINY;
+                    for (int k = m - 1; k >= 0; --k) {
+                        double temp;
+                        if (k <= m - 3) temp = x[k] - bb[k] * x[k + 1] - dd[k] * x[k + 2];
+                        else if (k == m - 2) temp = x[k] - bb[k] * x[k + 1];
+                        else temp = x[k];
+                        double ak = a[k];
+                        double pert = (ak != 0.0) ? copysign(tol, ak) : tol;
+                        for (int guard = 0; guard < 2000; ++guard) {
+                            const double absak = fabs(ak);
+                            if (absak < 1.0) {
+                                if (absak < DTINY) {
+                                    if (absak == 0.0 || fabs(temp) * DTINY > absak) { ak += pert; pert *= 2.0; continue; }
+                                    temp *= bignum; ak *= bignum;
+                                } else if (fabs(temp) > absak * bignum) { ak += pert; pert *= 2.0; continue; }
+                            }
+                            break;
+                        }
+                        x[k] = temp / ak;
+                    }
+                }
+                __syncthreads();
+                // ---- reorthogonalise inside the cluster (modified Gram-Schmidt against the finished vectors)
+                for (int i2 = j0; i2 < j; ++i2) {
+                    const double *zi = Zt + (size_t)i2 * n + s;
+                    double dot = 0.0;
+                    for (int i = lane; i < m; i += WAVE) dot += x[i] * zi[i];
+                    dot = wave_sum(dot);
+                    for (int i = lane; i < m; i += WAVE) x[i] -= dot * zi[i];
+                    __syncthreads();
+                }
+                double mx = 0.0;
+                for (int i = lane; i < m; i += WAVE) mx = fmax(mx, fabs(x[i]));
+                mx = wave_max(mx);
+                if (mx < stpcrt) continue;
+                if (++nrmchk < 3) continue;
+                ok = true;
+                break;
+            }
+            if (!ok && lane == 0) atomicAdd(&fail_[b], 1);
+            double n2 = 0.0;
+            for (int i = lane; i < m; i += WAVE) n2 += x[i] * x[i];
+            n2 = wave_sum(n2);
+            const double inv = 1.0 / sqrt(n2);
+            for (int i = lane; i < m; i += WAVE) z[s + i] = x[i] * inv;
+            __threadfence_block();
+            __syncthreads();
+            xjm = xj;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// V = Q Z.  grid (ceil(n/16), batch), block 256 = 4 waves x 4 vectors; each lane keeps NPER slices of its 4 vectors.
+template <int NPER>
+__global__ void __launch_bounds__(256) k_tri_backtrans(int n, const double *__restrict__ A_, const double *__restrict__ TAU_,
+                                                       double *__restrict__ Zt_) {
+    __shared__ double sv[2][64 * NPER];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
+    const double *A = A_ + (size_t)b * n * n, *TAU = TAU_ + (size_t)b * n;
+    double *Zt = Zt_ + (size_t)b * n * n;
+    const int j0 = blockIdx.x * 16 + wid * 4;
+    double z[4][NPER];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) {
+            const int i = lane + u * WAVE, j = j0 + q;
+            z[q][u] = (j < n && i < n) ? Zt[(size_t)j * n + i] : 0.0;
+        }
+    // reflector k acts on components k+1 .. n-1; applied in the order k = n-3 .. 0  (Q = H_0 H_1 ... H_{n-3})
+    int buf = 0;
+    for (int k = n - 3; k >= 0; --k) {
+        // stage v_k (full length n, zero above k+1) through LDS
+        for (int i = tid; i < 64 * NPER; i += 256) {
+            double v = 0.0;
+            if (i == k + 1) v = 1.0; else if (i > k + 1 && i < n) v = A[(size_t)k * n + i];
+            sv[buf][i] = v;
+        }
+        __syncthreads();
+        const double tau = TAU[k];
+        if (tau != 0.0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double dot = 0.0;
+#pragma unroll
+                for (int u = 0; u < NPER; ++u) dot += sv[buf][lane + u * WAVE] * z[q][u];
+                dot = wave_sum(dot) * tau;
+#pragma unroll
+                for (int u = 0; u < NPER; ++u) z[q][u] -= dot * sv[buf][lane + u * WAVE];
+            }
+        }
+        buf ^= 1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int u = 0; u < NPER; ++u) {
+            const int i = lane + u * WAVE, j = j0 + q;
+            if (j < n && i < n) Zt[(size_t)j * n + i] = z[q][u];
+        }
+}
+
+// ascending sort of WT -> W, perm (same contract as k_jac_finalize); dynamic LDS npow2 * 12 bytes
+__global__ void __launch_bounds__(256) k_tri_sort(int n, int npow2, const double *__restrict__ WT_, const int *__restrict__ fail_,
+                                                  double *__restrict__ W, int *__restrict__ perm, int *__restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *key = sm;
+    int *idx = (int *)(sm + npow2);
+    const int b = blockIdx.x;
+    int bad = 0;
+    for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+        if (i < n) { key[i] = WT_[(size_t)b * n + i]; idx[i] = i; if (!isfinite(key[i])) bad = 1; }
+        else { key[i] = INFINITY; idx[i] = -1; }
+    }
+    bad = __syncthreads_or(bad);
+    for (int kk = 2; kk <= npow2; kk <<= 1) {
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = ((i & kk) == 0);
+                    const double ki = key[i], kl = key[l];
+                    const bool gt = (ki > kl) || (ki == kl && idx[i] > idx[l]) || (ki != ki && kl == kl);
+                    if (gt == up) { key[i] = kl; key[l] = ki; const int t = idx[i]; idx[i] = idx[l]; idx[l] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { W[(size_t)b * n + i] = key[i]; perm[(size_t)b * n + i] = idx[i]; }
+    if (threadIdx.x == 0) { info[2 * b] = 0; info[2 * b + 1] = bad | (fail_[b] ? 4 : 0); }
+}
+
+}  // namespace mopt
+
+static int g_tri_attr = 0;
+
+// A is destroyed (reflectors are left in its rows).  Work arrays: d_D, d_E, d_TAU, d_WT, d_onenrm: batch*n doubles each;
+// d_bstart, d_bend, d_cstart: batch*n ints; d_ncl, d_fail: batch ints.
+int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
+                             double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
+                             double *d_W, int *d_perm, int *d_info) {
+    using namespace mopt;
+    if (n < 3) { ctx->err = "tridiagonal eigen-solver needs n >= 3"; return MOPT_E_ARG; }
+    if (!g_tri_attr) {
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_invit, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+        g_tri_attr = 1;
+    }
+    {
+        mopt_scope sc(ctx, "eigh_tridiag", 1);
+        hipLaunchKernelGGL(k_tridiag, dim3(batch), dim3(1024), (size_t)19 * n * 8, ctx->stream, n, getenv("MOPT_TRI_DBG") ? atoi(getenv("MOPT_TRI_DBG")) : 0, d_A, d_D, d_E, d_TAU);
+    }
+    {
+        mopt_scope sc(ctx, "eigh_bisect", 1);
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
+        hipLaunchKernelGGL(k_tri_bisect, dim3(batch), dim3(256), (size_t)3 * n * 8 + (size_t)2 * n * 4, ctx->stream, n, d_D, d_E, d_WT,
+                           d_bstart, d_bend, d_cstart, d_ncl, d_onenrm);
+    }
+    {
+        mopt_scope sc(ctx, "eigh_invit", 1);
+        const size_t perwave = ((size_t)5 * n + (n + 1) / 2 + 2) * 8;
+        hipLaunchKernelGGL(k_tri_invit, dim3(n, batch), dim3(64), perwave, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_cstart,
+                           d_ncl, d_onenrm, d_Vt, d_fail);
+    }
+    {
+        mopt_scope sc(ctx, "eigh_backtrans", 1);
+        const int nper = (n + 63) / 64;
+        const dim3 g((n + 15) / 16, batch);
+#define BT(NP) hipLaunchKernelGGL(k_tri_backtrans<NP>, g, dim3(256), 0, ctx->stream, n, d_A, d_TAU, d_Vt)
+        if (nper <= 1) BT(1); else if (nper <= 2) BT(2); else if (nper <= 3) BT(3); else if (nper <= 4) BT(4); else if (nper <= 5) BT(5);
+        else if (nper <= 6) BT(6); else if (nper <= 8) BT(8); else if (nper <= 10) BT(10); else if (nper <= 12) BT(12); else if (nper <= 16) BT(16);
+        else BT(24);
+#undef BT
+    }
+    {
+        mopt_scope sc(ctx, "eigh_final", 1);
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        hipLaunchKernelGGL(k_tri_sort, dim3(batch), dim3(256), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_WT, d_fail, d_W, d_perm, d_info);
+    }
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}

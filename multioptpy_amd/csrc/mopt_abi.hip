@@ -159,6 +159,16 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     TRY(dsig.alloc(ctx, batch * sizeof(double))); TRY(drot.alloc(ctx, (size_t)batch * (JAC_MAX_SWEEPS + 1) * sizeof(int)));
     TRY(dW.alloc(ctx, nv)); TRY(dperm.alloc(ctx, (size_t)batch * n * sizeof(int))); TRY(dinfo.alloc(ctx, (size_t)batch * 2 * sizeof(int)));
     H2D(ctx, dA.p, A, nn);
+    if (mopt_eigh_algo() == 1 && n >= 3) {
+        DBuf dsc, dsi;
+        const size_t nvi = (size_t)batch * n;
+        TRY(dsc.alloc(ctx, 5 * nvi * 8)); TRY(dsi.alloc(ctx, (3 * nvi + 2 * batch) * 4));
+        double *sc = dsc.as<double>();
+        int *si = dsi.as<int>();
+        TRY(mopt_launch_eigh_tridiag(ctx, n, batch, dA.as<double>(), dVt.as<double>(), sc, sc + nvi, sc + 2 * nvi, sc + 3 * nvi, sc + 4 * nvi,
+                                     si, si + nvi, si + 2 * nvi, si + 3 * nvi, si + 3 * nvi + batch, dW.as<double>(), dperm.as<int>(), dinfo.as<int>()));
+        MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    } else
     TRY(mopt_launch_eigh(ctx, n, batch, dA.as<double>(), dsig.as<double>(), dG.as<double>(), dVt.as<double>(), drot.as<int>(),
                          dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), MOPT_DEFAULT_SWEEPS, false));
     TRY(mopt_launch_eig_gather(ctx, n, batch, dVt.as<double>(), dperm.as<int>(), dV.as<double>()));

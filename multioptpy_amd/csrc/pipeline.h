@@ -10,6 +10,9 @@ namespace mopt {
 constexpr int JAC_MAX_SWEEPS = 30;
 }
 
+// scratch of the reduction-route eigen-solver (k_tridiag.hip)
+struct TriScratch { double *D, *E, *TAU, *WT, *onenrm; int *bstart, *bend, *cstart, *ncl, *fail; };
+
 // Device workspace of one batched RSIRFO.run (all pointers are device pointers).
 struct RsirfoWork {
     mopt_ctx *ctx = nullptr;
@@ -26,6 +29,7 @@ struct RsirfoWork {
     mopt::UpdateCoef *coef = nullptr;
     mopt_rsirfo_params *params = nullptr;
     mopt_rsirfo_state *states = nullptr;
+    TriScratch tri = {};
     int alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool with_bias, bool with_inplace);
     ~RsirfoWork();
 };
@@ -51,6 +55,11 @@ int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
                      int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps, bool warm);
 int mopt_launch_dgemm(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_B, const double *d_addscale, double *d_C);
+int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
+                             double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
+                             double *d_W, int *d_perm, int *d_info);
+// algorithm switch: 0 = block Jacobi (k_eigh.hip), 1 = tridiagonal reduction route (k_tridiag.hip); env MOPT_EIGH_ALGO overrides
+int mopt_eigh_algo();
 int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const int *d_perm, double *d_V);
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,

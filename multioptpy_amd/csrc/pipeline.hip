@@ -1,4 +1,5 @@
 // Batched RSIRFO.run pipeline on device buffers (multioptpy/Optimizer/rsirfo.py:285-490).
+#include <cstdlib>
 #include "pipeline.h"
 
 RsirfoWork::~RsirfoWork() {
@@ -17,6 +18,7 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
     tot += al(nv * 4);                 // perm
     tot += 3 * al((size_t)batch * 8) + al((size_t)batch * 8 * 8);
     tot += al((size_t)batch * 2 * 4) + al((size_t)batch * (mopt::JAC_MAX_SWEEPS + 1) * 4) + 2 * al((size_t)batch * 4);
+    tot += 5 * al(nv * 8) + 3 * al(nv * 4) + 2 * al((size_t)batch * 4);      // reduction-route eigen-solver scratch
     tot += al(batch * sizeof(mopt::UpdateCoef)) + al(batch * sizeof(mopt_rsirfo_params)) + al(batch * sizeof(mopt_rsirfo_state));
     if (hipMalloc(&block, tot) != hipSuccess) { c->err = "hipMalloc failed (RSIRFO workspace)"; block = nullptr; return MOPT_E_NOMEM; }
     char *p = (char *)block;
@@ -38,6 +40,10 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
     coef = (mopt::UpdateCoef *)take(batch * sizeof(mopt::UpdateCoef));
     params = (mopt_rsirfo_params *)take(batch * sizeof(mopt_rsirfo_params));
     states = (mopt_rsirfo_state *)take(batch * sizeof(mopt_rsirfo_state));
+    tri.D = (double *)take(nv * 8); tri.E = (double *)take(nv * 8); tri.TAU = (double *)take(nv * 8); tri.WT = (double *)take(nv * 8);
+    tri.onenrm = (double *)take(nv * 8);
+    tri.bstart = (int *)take(nv * 4); tri.bend = (int *)take(nv * 4); tri.cstart = (int *)take(nv * 4);
+    tri.ncl = (int *)take((size_t)batch * 4); tri.fail = (int *)take((size_t)batch * 4);
     return MOPT_OK;
 }
 
@@ -55,9 +61,25 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     if (rc != MOPT_OK) return rc;
     rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A);
     if (rc != MOPT_OK) return rc;
-    rc = mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm_eigh);
+    if (mopt_eigh_algo() == 1 && n >= 3) {
+        // reduction route: work on a copy (the reflectors overwrite it), eigenvectors land in Vt
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.Gt, wk.A, (size_t)batch * n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        rc = mopt_launch_eigh_tridiag(ctx, n, batch, wk.Gt, wk.Vt, wk.tri.D, wk.tri.E, wk.tri.TAU, wk.tri.WT, wk.tri.onenrm, wk.tri.bstart,
+                                      wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo);
+    } else {
+        rc = mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm_eigh);
+    }
     if (rc != MOPT_OK) return rc;
     rc = mopt_launch_rfo(ctx, n, batch, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, wk.gp, wk.bg, wk.be, coef,
                          wk.gt_all, wk.coefout, wk.step);
     return rc;
+}
+
+int mopt_eigh_algo() {
+    static int algo = -1;
+    if (algo < 0) {
+        const char *e = getenv("MOPT_EIGH_ALGO");
+        algo = (e && (e[0] == 't' || e[0] == '1')) ? 1 : 0;
+    }
+    return algo;
 }

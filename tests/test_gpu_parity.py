@@ -82,7 +82,7 @@ def test_eigh_random(ops, n):
     assert np.abs(w - wr).max() < 1e-13 * nrm, (n, np.abs(w - wr).max())
     assert np.abs(v.T @ v - np.eye(n)).max() < 1e-12
     assert np.abs(A @ v - v * w).max() < 5e-12 * nrm
-    assert 1 <= sw[0] <= 16
+    assert 0 <= sw[0] <= 16        # 0: the reduction route reports no sweeps
 
 
 def test_eigh_degenerate_and_batched(ops):
@@ -337,3 +337,47 @@ def test_rsprfo_traces_vs_reference():
             if opt.saddle_order == 1:
                 assert (opt.ts_mode_idx is None and ts == -1) or int(opt.ts_mode_idx) == ts, (tag, k)
     print("RSPRFO worst step deviation from the reference:", worst)
+
+
+def test_eigh_reduction_route(ops):
+    """The tridiagonal-reduction eigen-solver (MOPT_EIGH_ALGO=tridiag): random, degenerate, clustered and LJ matrices."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests", "golden"))
+import cases
+from multioptpy_amd import ops
+from oracle import projection as pj
+rng = np.random.default_rng(0)
+mats = {}
+for n in (3, 21, 66, 150, 300):
+    R = rng.normal(size=(n, n)); mats[f"random{n}"] = 0.5 * (R + R.T)
+N = 22; n = 3 * N; x = cases.cluster(N)
+mats["projI"] = pj.project_hessian_trrot(np.eye(n), x)
+mats["lj22"] = pj.project_hessian_trrot(cases.lj(x, hessian=True)[2], x)
+mats["diag"] = np.diag(np.linspace(-1, 2, n))
+Q, _ = np.linalg.qr(rng.normal(size=(60, 60)))
+lam = np.concatenate([np.ones(20), 1 + 1e-9 * rng.normal(size=20), np.linspace(2, 3, 20)])
+mats["clustered"] = (Q * lam) @ Q.T
+x100 = cases.cluster(100)
+mats["lj100"] = pj.project_hessian_trrot(cases.lj(x100, hessian=True)[2], x100)
+bad = 0
+for name, A in mats.items():
+    w, v = ops.eigh(A)
+    wr = np.linalg.eigvalsh(A)
+    nrm = max(np.abs(A).sum(axis=1).max(), 1e-300)
+    e1 = np.abs(w - wr).max() / nrm; e2 = np.abs(v.T @ v - np.eye(len(w))).max(); e3 = np.abs(A @ v - v * w).max() / nrm
+    print(f"{name:12s} eig {e1:.2e} orth {e2:.2e} resid {e3:.2e}")
+    if not (e1 < 1e-13 and e2 < 1e-11 and e3 < 1e-12): bad += 1
+B = np.array([mats["lj22"], mats["projI"], mats["diag"]])
+w, v = ops.eigh(B)
+for b in range(3):
+    assert np.abs(w[b] - np.linalg.eigvalsh(B[b])).max() < 1e-13 * max(1.0, np.abs(B[b]).sum(axis=1).max())
+sys.exit(bad)
+'''
+    env = dict(os.environ, MOPT_EIGH_ALGO="tridiag")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    print(r.stdout)
+    print(r.stderr[-2000:])
+    assert r.returncode == 0
