@@ -110,6 +110,145 @@ __global__ void __launch_bounds__(1024) k_tridiag(int n, int dbg, double *__rest
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Multi-workgroup tridiagonalisation: ONE launch per Householder step, TRI_G workgroups per matrix, the kernel boundary is
+// the grid-wide synchronisation (no in-kernel inter-workgroup hand-off).  Launch k (k = -1 .. n-3) fuses
+//   (a) the rank-2 update of step k:        A22 -= v w^T + w v^T                      (skipped for k = -1)
+//   (b) the reflector of step k+1 from the freshly updated row k+1                    (every workgroup, redundantly)
+//   (c) the SYMV of step k+1:  partial p' = (rows of this workgroup) . v'             (one partial vector per workgroup)
+// so every trailing element is read and written once per step.  Global rows are dealt to the TRI_G workgroups in chunks of
+// 8 (cyclic), which fixes the summation order independently of the batch size.
+constexpr int TRI_G = 8;
+constexpr int TRI_RC = 8;
+
+// state per matrix: V[n] current reflector (index = global row), PART[TRI_G][n] partial SYMV, SC[4] = {tau_k}
+// Double buffering: launch k reads reflector / partial buffers (k & 1) and writes ((k + 1) & 1), so a fast workgroup can
+// never overwrite what a slow one is still reading; row k+1 of A is only read (prologue) and receives its reflector one
+// launch later.
+__global__ void __launch_bounds__(1024) k_tri_step(int n, int k, double *__restrict__ A_, double *__restrict__ D_, double *__restrict__ E_,
+                                                   double *__restrict__ TAU_, double *__restrict__ V0_, double *__restrict__ V1_,
+                                                   double *__restrict__ PART_) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[2 * 16];
+    double *sv = sm, *sw = sm + n, *svn = sm + 2 * n;       // v_k, w_k, v_{k+1}  (indexed by global row/column)
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    double *A = A_ + (size_t)b * n * n;
+    double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
+    const int cur = k & 1, nxt = cur ^ 1;
+    const double *V = (cur ? V1_ : V0_) + (size_t)b * n;
+    double *Vn = (nxt ? V1_ : V0_) + (size_t)b * n;
+    const double *PART = PART_ + ((size_t)b * 2 + cur) * TRI_G * n;
+    double *PARTn = PART_ + ((size_t)b * 2 + nxt) * TRI_G * n;
+    const int lo = k + 1;                                   // first row/column of the trailing matrix of step k
+    // ---- prologue.  All global reads of the prologue (tau_k, v_k, the TRI_G partial vectors, row lo of A) are issued
+    // together: most of them were written by other XCDs in the previous launch and cost a fabric round trip each.
+    const int nk = k + 1;                                    // step whose reflector is built now
+    const bool build = (nk <= n - 2);
+    double tau = (k >= 0) ? TAU[k] : 0.0;
+    // each thread owns columns j = lo + tid + q * blockDim (at most TRI_JP of them)
+    constexpr int TRI_JP = 4;
+    double r_v[TRI_JP], r_p[TRI_JP], r_row[TRI_JP];
+#pragma unroll
+    for (int q = 0; q < TRI_JP; ++q) {
+        const int j = lo + tid + q * (int)blockDim.x;
+        r_v[q] = 0.0; r_p[q] = 0.0; r_row[q] = 0.0;
+        if (j < n) {
+            if (k >= 0) {
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < TRI_G; ++u) acc += PART[(size_t)u * n + j];
+                r_p[q] = acc;
+                r_v[q] = V[j];
+            }
+            if (build) r_row[q] = A[(size_t)lo * n + j];
+        }
+    }
+    if (k >= 0) {
+        double pv = 0.0;
+#pragma unroll
+        for (int q = 0; q < TRI_JP; ++q) {
+            const int j = lo + tid + q * (int)blockDim.x;
+            if (j < n) { const double pj = tau * r_p[q]; sv[j] = r_v[q]; sw[j] = pj; pv += pj * r_v[q]; }
+        }
+        pv = block_sum1(pv, red);
+        const double c = -0.5 * tau * pv;
+#pragma unroll
+        for (int q = 0; q < TRI_JP; ++q) {
+            const int j = lo + tid + q * (int)blockDim.x;
+            if (j < n) sw[j] = sw[j] + c * sv[j];
+        }
+        __syncthreads();
+    }
+    // ---- reflector of step k+1 from the updated row lo (global index), x = row[lo+1 ..]
+    double taun = 0.0, betan = 0.0;
+    if (build) {
+        double part = 0.0;
+#pragma unroll
+        for (int q = 0; q < TRI_JP; ++q) {
+            const int j = lo + tid + q * (int)blockDim.x;
+            if (j < n) {
+                double r = r_row[q];
+                if (k >= 0 && tau != 0.0) r -= sv[lo] * sw[j] + sw[lo] * sv[j];
+                svn[j] = r;                                   // updated row lo (raw, before scaling)
+                if (j >= lo + 2) part += r * r;
+            }
+        }
+        const double xn2 = block_sum1(part, red);
+        __syncthreads();
+        const double alpha = (lo + 1 < n) ? svn[lo + 1] : 0.0;
+        const double diag = svn[lo];
+        const double xnorm = sqrt(xn2);
+        double scal = 0.0;
+        betan = alpha;
+        if (nk <= n - 3 && xnorm != 0.0) {
+            betan = -copysign(hypot(alpha, xnorm), alpha);
+            taun = (betan - alpha) / betan;
+            scal = 1.0 / (alpha - betan);
+        }
+        __syncthreads();
+        for (int j = lo + 1 + tid; j < n; j += blockDim.x) svn[j] = (j == lo + 1) ? 1.0 : svn[j] * scal;
+        if (tid == 0) svn[lo] = 0.0;
+        __syncthreads();
+        if (g == 0 && tid == 0) { D[nk] = diag; E[nk] = betan; TAU[nk] = taun; if (nk == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; } }
+        if (g == 0) for (int j = lo + 1 + tid; j < n; j += blockDim.x) Vn[j] = svn[j];
+    }
+    // the reflector of step k goes into row k of A (columns k+2 ..) as dsytrd keeps it; nobody reads that row any more
+    if (k >= 0 && g == 0) for (int j = k + 2 + tid; j < n; j += blockDim.x) A[(size_t)k * n + j] = sv[j];
+    // ---- main pass over the rows of this workgroup: update with (v, w), accumulate the next SYMV with v'
+    const bool do_upd = (k >= 0 && tau != 0.0);
+    const bool do_mv = build && (taun != 0.0);
+    for (int jb = 0; jb < n; jb += blockDim.x) {
+        const int j = jb + tid;
+        double acc = 0.0;
+        if (j > lo && j < n) {
+            const double wj = do_upd ? sw[j] : 0.0, vj = do_upd ? sv[j] : 0.0;
+            for (int c0 = ((lo + 1) / TRI_RC); c0 * TRI_RC < n; ++c0) {
+                if ((c0 % TRI_G) != g) continue;
+                const int i0 = c0 * TRI_RC > lo + 1 ? c0 * TRI_RC : lo + 1, i1 = (c0 + 1) * TRI_RC < n ? (c0 + 1) * TRI_RC : n;
+                double x[TRI_RC];
+#pragma unroll
+                for (int q = 0; q < TRI_RC; ++q) { const int i = i0 + q; x[q] = (i < i1) ? A[(size_t)i * n + j] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < TRI_RC; ++q) {
+                    const int i = i0 + q;
+                    if (i < i1) {
+                        double a = x[q];
+                        if (do_upd) { a -= sv[i] * wj + sw[i] * vj; A[(size_t)i * n + j] = a; }
+                        if (do_mv) acc += a * svn[i];
+                    }
+                }
+            }
+        }
+        if (j < n) PARTn[(size_t)g * n + j] = acc;
+    }
+}
+
+// D[n-1] after the last update (tiny)
+__global__ void k_tri_last(int n, const double *__restrict__ A_, double *__restrict__ D_) {
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) D_[(size_t)b * n + n - 1] = A_[(size_t)b * n * n + (size_t)(n - 1) * n + (n - 1)];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // number of eigenvalues of the block (d[s..t), off-diagonals e2 = e^2) that are < x
 __device__ __forceinline__ int sturm_count(const double *d, const double *e2, int s, int t, double x, double pivmin) {
     int cnt = 0;
@@ -434,7 +573,17 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
         g_tri_attr = 1;
     }
-    {
+    const bool multi = !(getenv("MOPT_TRI_SINGLE")) && n >= 32;
+    if (multi) {
+        mopt_scope sc(ctx, "eigh_tridiag", n);
+        int bt = ((n + 63) / 64) * 64;          // one thread per column (up to 4 columns per thread: n <= 4096)
+        if (bt > 1024) bt = 1024;
+        // reflector double buffer in d_onenrm / d_WT (free until the bisection), partial-SYMV double buffer in d_Vt (free until k_tri_invit)
+        for (int k = -1; k <= n - 3; ++k)
+            hipLaunchKernelGGL(k_tri_step, dim3(TRI_G, batch), dim3(bt), (size_t)3 * n * 8, ctx->stream, n, k, d_A, d_D, d_E, d_TAU, d_onenrm, d_WT,
+                               d_Vt);
+        hipLaunchKernelGGL(k_tri_last, dim3(batch), dim3(64), 0, ctx->stream, n, d_A, d_D);
+    } else {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         hipLaunchKernelGGL(k_tridiag, dim3(batch), dim3(1024), (size_t)19 * n * 8, ctx->stream, n, getenv("MOPT_TRI_DBG") ? atoi(getenv("MOPT_TRI_DBG")) : 0, d_A, d_D, d_E, d_TAU);
     }
