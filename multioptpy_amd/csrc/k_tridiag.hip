@@ -242,6 +242,182 @@ __global__ void __launch_bounds__(1024) k_tri_step(int n, int k, double *__restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Persistent tridiagonalisation: the same fused step as k_tri_step, but ONE launch for all n-1 steps.  Workgroup (g, b) keeps
+// its rows of matrix b (8-row chunks dealt cyclically over the G workgroups of the matrix) in LDS for the whole reduction, so
+// the matrix never travels again: per step only G partial SYMV vectors and one matrix row cross the fabric.
+// Hand-off between the G workgroups of a matrix uses self-validating words instead of a barrier (the "LL" scheme of the
+// collective libraries): every double travels as two 64-bit words {low half | tag << 32}, {high half | tag << 32}, written
+// with agent-scope atomic stores and polled with agent-scope atomic loads; tag = step + 2, buffers zeroed before the launch.
+// A consumer therefore never sees a torn or stale value, and one fabric round trip carries both data and "ready".
+// Buffers are double-buffered by step parity: a workgroup can only write tag t+2 into a buffer after it has consumed every
+// partner's tag t+1, which partners only produce after they have finished reading tag t -- so nothing is overwritten early.
+// Requires G * nbatch <= #CUs (one workgroup per CU by LDS size) so that all participants are resident; every poll is bounded.
+typedef unsigned long long u64;
+__device__ __forceinline__ void ll_put(u64 *p, double v, unsigned tag) {
+    const u64 bits = (u64)__double_as_longlong(v), t = (u64)tag << 32;
+    __hip_atomic_store(p, (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ll_ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ll_val(u64 a, u64 c) { return __longlong_as_double((long long)((a & 0xffffffffull) | (c << 32))); }
+constexpr unsigned LL_SPIN_LIMIT = 2000000u;
+
+// thread layout: cols = roundup64(n) column threads x RG row groups (wave-uniform); one column per thread (n <= 1024)
+__global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap, int cols, int RG, double *__restrict__ A_,
+                                                      double *__restrict__ D_, double *__restrict__ E_, double *__restrict__ TAU_,
+                                                      u64 *__restrict__ XCH_, size_t xch_stride, int *__restrict__ fail_) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[2 * 16];
+    __shared__ int s_fail;
+    double *sva = sm, *sw = sm + n, *svb = sm + 2 * n;      // reflector ping-pong (sva/svb), w
+    double *accp = sm + 3 * n;                              // [RG][n] partial SYMV per row group
+    double *Aloc = sm + (size_t)(3 + RG) * n;               // [rows_cap][n] rows owned by this workgroup
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int j = tid % cols, rg = tid / cols;
+    double *A = A_ + (size_t)b * n * n;
+    double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
+    u64 *PARTX = XCH_ + (size_t)b * xch_stride;             // [2][G][n][2]
+    u64 *ROWX = PARTX + (size_t)4 * G * n;                  // [2][n][2]
+    // local row r  <->  global row:  chunk q = r / 8 (local), global chunk c = g + q * G, row = c * 8 + r % 8
+    if (tid == 0) s_fail = 0;
+    for (int r = rg; r < rows_cap; r += RG) {
+        const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+        if (j < n) Aloc[(size_t)r * n + j] = (gi < n) ? A[(size_t)gi * n + j] : 0.0;
+    }
+    __syncthreads();
+    // the owner of row 0 publishes it: step k consumes tag k + 2 from buffer (k & 1); k = -1 reads buffer 1
+    if (g == 0 && rg == 0 && j < n) ll_put(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u);
+    double tau = 0.0, taun = 0.0;
+    double *sv = sva, *svn = svb;
+    for (int k = -1; k <= n - 3; ++k) {
+        const int lo = k + 1, cur = k & 1, nxt = cur ^ 1;
+        const int nk = k + 1;
+        const bool build = (nk <= n - 2);
+        const unsigned tag = (unsigned)(k + 2);
+        const u64 *PARTc = PARTX + (size_t)cur * G * n * 2;
+        u64 *PARTn = PARTX + (size_t)nxt * G * n * 2;
+        const u64 *ROWc = ROWX + (size_t)cur * n * 2;
+        u64 *ROWn = ROWX + (size_t)nxt * n * 2;
+        // ---- collect: the G partial SYMV vectors of step k and row lo, column j
+        double psum = 0.0, rowj = 0.0;
+        if (rg == 0 && j >= lo && j < n) {
+            if (k >= 0) {
+                for (int u0 = 0; u0 < G; u0 += 8) {              // G is a multiple of 8: sixteen loads in flight
+                    u64 a[8], c[8];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const u64 *q = &PARTc[((size_t)(u0 + u) * n + j) * 2];
+                            a[u] = ll_ld(q); c[u] = ll_ld(q + 1);
+                        }
+                        bool ok = true;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ok = ok && ((unsigned)(a[u] >> 32) == tag) && ((unsigned)(c[u] >> 32) == tag);
+                        if (ok) break;
+                        if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) psum += ll_val(a[u], c[u]);
+                }
+            }
+            if (build) {
+                u64 a, c;
+                unsigned spins = 0;
+                for (;;) {
+                    const u64 *q = &ROWc[(size_t)j * 2];
+                    a = ll_ld(q); c = ll_ld(q + 1);
+                    if ((unsigned)(a >> 32) == tag && (unsigned)(c >> 32) == tag) break;
+                    if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                rowj = ll_val(a, c);
+            }
+        }
+        __syncthreads();
+        if (s_fail) break;
+        // ---- w_k
+        if (k >= 0) {
+            double pv = 0.0;
+            const bool mine = (rg == 0 && j >= lo && j < n);
+            const double pj = tau * psum;
+            if (mine) { sw[j] = pj; pv = pj * sv[j]; }
+            pv = block_sum1(pv, red);
+            const double c = -0.5 * tau * pv;
+            if (mine) sw[j] = pj + c * sv[j];
+            __syncthreads();
+        }
+        // ---- reflector of step k+1 from the updated row lo
+        double betan = 0.0;
+        taun = 0.0;
+        if (build) {
+            double part = 0.0;
+            if (rg == 0 && j >= lo && j < n) {
+                double r = rowj;
+                if (k >= 0 && tau != 0.0) r -= sv[lo] * sw[j] + sw[lo] * sv[j];
+                svn[j] = r;
+                if (j >= lo + 2) part = r * r;
+            }
+            const double xn2 = block_sum1(part, red);
+            __syncthreads();
+            const double alpha = (lo + 1 < n) ? svn[lo + 1] : 0.0;
+            const double diag = svn[lo];
+            const double xnorm = sqrt(xn2);
+            double scal = 0.0;
+            betan = alpha;
+            if (nk <= n - 3 && xnorm != 0.0) {
+                betan = -copysign(hypot(alpha, xnorm), alpha);
+                taun = (betan - alpha) / betan;
+                scal = 1.0 / (alpha - betan);
+            }
+            __syncthreads();
+            if (rg == 0 && j >= lo && j < n) svn[j] = (j == lo) ? 0.0 : (j == lo + 1) ? 1.0 : svn[j] * scal;
+            __syncthreads();
+            if (g == 0 && tid == 0) { D[nk] = diag; E[nk] = betan; TAU[nk] = taun; if (nk == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; } }
+        }
+        if (k >= 0 && g == 0 && rg == RG - 1 && j >= k + 2 && j < n) A[(size_t)k * n + j] = sv[j];   // reflector k, dsytrd layout
+        // ---- main pass over the rows kept in LDS: rank-2 update with (v, w), next SYMV with v'
+        const bool do_upd = (k >= 0 && tau != 0.0);
+        const bool do_mv = build && (taun != 0.0);
+        double acc = 0.0;
+        if (j > lo && j < n) {
+            const double wj = do_upd ? sw[j] : 0.0, vj = do_upd ? sv[j] : 0.0;
+            for (int r = rg; r < rows_cap; r += RG) {
+                const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+                if (gi <= lo || gi >= n) continue;
+                double a = Aloc[(size_t)r * n + j];
+                if (do_upd) { a -= sv[gi] * wj + sw[gi] * vj; Aloc[(size_t)r * n + j] = a; }
+                if (do_mv) acc += a * svn[gi];
+                if (gi == lo + 1) ll_put(&ROWn[(size_t)j * 2], a, tag + 1u);       // (only the owner holds this row)
+            }
+        }
+        if (RG > 1) {
+            if (j < n) accp[(size_t)rg * n + j] = acc;
+            __syncthreads();
+            if (rg == 0 && j < n) {
+                acc = 0.0;
+                for (int q = 0; q < RG; ++q) acc += accp[(size_t)q * n + j];
+            }
+        }
+        if (rg == 0 && j > lo && j < n) ll_put(&PARTn[((size_t)g * n + j) * 2], acc, tag + 1u);
+        tau = taun;
+        { double *t = sv; sv = svn; svn = t; }
+        __syncthreads();
+    }
+    if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
+    // D[n-1]: owner of the last row
+    {
+        const int gi_last = n - 1;
+        const int c = gi_last / TRI_RC;
+        if (c % G == g && tid == 0 && !s_fail) {
+            const int r = (c / G) * TRI_RC + (gi_last % TRI_RC);
+            D[n - 1] = Aloc[(size_t)r * n + (n - 1)];
+        }
+    }
+}
+
 // D[n-1] after the last update (tiny)
 __global__ void k_tri_last(int n, const double *__restrict__ A_, double *__restrict__ D_) {
     const int b = blockIdx.x;
@@ -559,7 +735,7 @@ __global__ void __launch_bounds__(256) k_tri_sort(int n, int npow2, const double
 
 }  // namespace mopt
 
-static int g_tri_attr = 0;
+static int g_tri_attr = 0, g_tri_attr2 = 0;
 
 // A is destroyed (reflectors are left in its rows).  Work arrays: d_D, d_E, d_TAU, d_WT, d_onenrm: batch*n doubles each;
 // d_bstart, d_bend, d_cstart: batch*n ints; d_ncl, d_fail: batch ints.
@@ -574,7 +750,36 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         g_tri_attr = 1;
     }
     const bool multi = !(getenv("MOPT_TRI_SINGLE")) && n >= 32;
-    if (multi) {
+    MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
+    // persistent LDS-resident variant: G workgroups per matrix with rows_cap * n doubles of LDS each
+    int G = 8;
+    const int cols = ((n + 63) / 64) * 64;
+    int RG = 1024 / cols;
+    if (RG < 1) RG = 1;
+    if (RG > 4) RG = 4;
+    auto rows_for = [&](int G_) { const int nch = (n + TRI_RC - 1) / TRI_RC; return ((nch + G_ - 1) / G_) * TRI_RC; };
+    auto lds_for = [&](int G_) { return ((size_t)rows_for(G_) * n + (size_t)(3 + RG) * n) * 8; };
+    while (G < 256 && lds_for(G) > (size_t)ctx->lds_limit - 4096) G *= 2;
+    const bool persist = multi && !getenv("MOPT_TRI_NOPERSIST") && lds_for(G) <= (size_t)ctx->lds_limit - 4096 && G <= ctx->num_cu &&
+                         n <= 1024 && 4 * G + 4 <= n;
+    if (persist) {
+        mopt_scope sc(ctx, "eigh_tridiag", 1);
+        if (!g_tri_attr2) {
+            MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_persist, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+            g_tri_attr2 = 1;
+        }
+        const int rows = rows_for(G);
+        const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
+        // exchange words live at the head of each matrix' slot of d_Vt (free until k_tri_invit): (4 G + 4) n 64-bit words <= n^2
+        const size_t xwords = ((size_t)4 * G + 4) * n;
+        MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
+        for (int b0 = 0; b0 < batch; b0 += per) {
+            const int nb_ = (batch - b0 < per) ? batch - b0 : per;
+            hipLaunchKernelGGL(k_tri_persist, dim3(G, nb_), dim3(cols * RG), lds_for(G), ctx->stream, n, G, rows, cols, RG,
+                               d_A + (size_t)b0 * n * n, d_D + (size_t)b0 * n, d_E + (size_t)b0 * n, d_TAU + (size_t)b0 * n,
+                               (u64 *)(d_Vt + (size_t)b0 * n * n), (size_t)n * n, d_fail + b0);
+        }
+    } else if (multi) {
         mopt_scope sc(ctx, "eigh_tridiag", n);
         int bt = ((n + 63) / 64) * 64;          // one thread per column (up to 4 columns per thread: n <= 4096)
         if (bt > 1024) bt = 1024;
@@ -589,7 +794,6 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     }
     {
         mopt_scope sc(ctx, "eigh_bisect", 1);
-        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_tri_bisect, dim3(batch), dim3(256), (size_t)3 * n * 8 + (size_t)2 * n * 4, ctx->stream, n, d_D, d_E, d_WT,
                            d_bstart, d_bend, d_cstart, d_ncl, d_onenrm);
     }
