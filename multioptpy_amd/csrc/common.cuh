@@ -13,15 +13,35 @@ namespace mopt {
 
 constexpr int WAVE = 64;
 
+// Cross-lane moves on the DPP path (no LDS traffic, unlike ds_bpermute behind __shfl): quad permutes, row mirrors, then the
+// row broadcasts of GFX9; lanes outside row_mask receive `old`.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+// Sum over the 64 lanes, returned to every lane.  Order: pairs, quads, half rows, rows (16 lanes), then rows 0+1, 2+3, all.
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
+    v += dpp_f64<0xB1, 0xF>(0.0, v);       // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(0.0, v);       // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(0.0, v);      // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(0.0, v);      // row_mirror
+    v += dpp_f64<0x142, 0xA>(0.0, v);      // row_bcast15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xC>(0.0, v);      // row_bcast31 into rows 2 and 3
+    return lane_bcast(v, 63);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
-    return v;
+    v = fmax(v, dpp_f64<0xB1, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x4E, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x141, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x140, 0xF>(v, v));
+    v = fmax(v, dpp_f64<0x142, 0xA>(v, v));
+    v = fmax(v, dpp_f64<0x143, 0xC>(v, v));
+    return lane_bcast(v, 63);
 }
 __device__ __forceinline__ int wave_min_int(int v) {
 #pragma unroll

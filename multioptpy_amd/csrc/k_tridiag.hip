@@ -8,6 +8,8 @@
 // ~ (4/3 + 2) n^3 flops instead of the ~70 n^3 of the Jacobi route (k_eigh.hip); same output contract:
 // W ascending, perm, Vt vector-major, einfo.
 #include <cstdlib>
+#include <cstdio>
+#include <vector>
 #include "pipeline.h"
 
 namespace mopt {
@@ -266,10 +268,12 @@ constexpr unsigned LL_SPIN_LIMIT = 2000000u;
 // thread layout: cols = roundup64(n) column threads x RG row groups (wave-uniform); one column per thread (n <= 1024)
 __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap, int cols, int RG, double *__restrict__ A_,
                                                       double *__restrict__ D_, double *__restrict__ E_, double *__restrict__ TAU_,
-                                                      u64 *__restrict__ XCH_, size_t xch_stride, int *__restrict__ fail_) {
+                                                      u64 *__restrict__ XCH_, size_t xch_stride, int *__restrict__ fail_,
+                                                      long long *__restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[2 * 16];
     __shared__ int s_fail;
+    long long t_poll = 0, t_pro = 0, t_main = 0, t0 = 0, t1 = 0;
     double *sva = sm, *sw = sm + n, *svb = sm + 2 * n;      // reflector ping-pong (sva/svb), w
     double *accp = sm + 3 * n;                              // [RG][n] partial SYMV per row group
     double *Aloc = sm + (size_t)(3 + RG) * n;               // [rows_cap][n] rows owned by this workgroup
@@ -301,6 +305,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         u64 *ROWn = ROWX + (size_t)nxt * n * 2;
         // ---- collect: the G partial SYMV vectors of step k and row lo, column j
         double psum = 0.0, rowj = 0.0;
+        if (prof) t0 = wall_clock64();
         if (rg == 0 && j >= lo && j < n) {
             if (k >= 0) {
                 for (int u0 = 0; u0 < G; u0 += 8) {              // G is a multiple of 8: sixteen loads in flight
@@ -338,6 +343,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         }
         __syncthreads();
         if (s_fail) break;
+        if (prof) { t1 = wall_clock64(); t_poll += t1 - t0; t0 = t1; }
         // ---- w_k
         if (k >= 0) {
             double pv = 0.0;
@@ -381,6 +387,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         // ---- main pass over the rows kept in LDS: rank-2 update with (v, w), next SYMV with v'
         const bool do_upd = (k >= 0 && tau != 0.0);
         const bool do_mv = build && (taun != 0.0);
+        if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
         double acc = 0.0;
         if (j > lo && j < n) {
             const double wj = do_upd ? sw[j] : 0.0, vj = do_upd ? sv[j] : 0.0;
@@ -405,7 +412,9 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         tau = taun;
         { double *t = sv; sv = svn; svn = t; }
         __syncthreads();
+        if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
     }
+    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 4; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; }
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
     // D[n-1]: owner of the last row
     {
@@ -755,6 +764,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     int G = 8;
     const int cols = ((n + 63) / 64) * 64;
     int RG = 1024 / cols;
+    if (getenv("MOPT_TRI_RG")) RG = atoi(getenv("MOPT_TRI_RG"));
     if (RG < 1) RG = 1;
     if (RG > 4) RG = 4;
     auto rows_for = [&](int G_) { const int nch = (n + TRI_RC - 1) / TRI_RC; return ((nch + G_ - 1) / G_) * TRI_RC; };
@@ -769,6 +779,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             g_tri_attr2 = 1;
         }
         const int rows = rows_for(G);
+        long long *d_prof = nullptr;
+        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 32); hipMemset(d_prof, 0, (size_t)batch * G * 32); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
         // exchange words live at the head of each matrix' slot of d_Vt (free until k_tri_invit): (4 G + 4) n 64-bit words <= n^2
         const size_t xwords = ((size_t)4 * G + 4) * n;
@@ -777,7 +789,17 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             const int nb_ = (batch - b0 < per) ? batch - b0 : per;
             hipLaunchKernelGGL(k_tri_persist, dim3(G, nb_), dim3(cols * RG), lds_for(G), ctx->stream, n, G, rows, cols, RG,
                                d_A + (size_t)b0 * n * n, d_D + (size_t)b0 * n, d_E + (size_t)b0 * n, d_TAU + (size_t)b0 * n,
-                               (u64 *)(d_Vt + (size_t)b0 * n * n), (size_t)n * n, d_fail + b0);
+                               (u64 *)(d_Vt + (size_t)b0 * n * n), (size_t)n * n, d_fail + b0, d_prof ? d_prof + (size_t)b0 * G * 4 : nullptr);
+        }
+        if (d_prof) {
+            std::vector<long long> h((size_t)batch * G * 4);
+            hipStreamSynchronize(ctx->stream);
+            hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
+            hipFree(d_prof);
+            double sp = 0, sr = 0, smn = 0;
+            for (int i = 0; i < batch * G; ++i) { sp += h[4 * i]; sr += h[4 * i + 1]; smn += h[4 * i + 2]; }
+            const double f = 0.01 / (batch * G) / (n - 1);     // 100 MHz ticks -> us per step
+            fprintf(stderr, "[tri_prof] n=%d G=%d RG=%d per step: poll %.2f us, prologue %.2f us, main %.2f us\n", n, G, RG, sp * f, sr * f, smn * f);
         }
     } else if (multi) {
         mopt_scope sc(ctx, "eigh_tridiag", n);
