@@ -30,7 +30,8 @@ enum {
     MOPT_E_ARG = -1,      /* bad argument (null pointer, size out of range, unknown rule) */
     MOPT_E_DEVICE = -2,   /* HIP runtime error (text in mopt_last_error) */
     MOPT_E_NOMEM = -3,
-    MOPT_E_STATE = -4     /* call sequence error (e.g. Hessian not set) */
+    MOPT_E_STATE = -4,    /* call sequence error (e.g. Hessian not set) */
+    MOPT_E_NUMERIC = -5   /* the eigen-solver reported failure for at least one matrix (outputs are written but must not be used) */
 };
 
 /* Hessian update rules = the dispatch keys of multioptpy/Optimizer/rsirfo.py:208-251 in

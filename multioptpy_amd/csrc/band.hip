@@ -231,6 +231,7 @@ struct mopt_band {
     double *gamma = nullptr, *rfo_delta = nullptr, *newX = nullptr, *wx = nullptr, *wg = nullptr;
     void *block = nullptr;
     bool have_prev = false, uploaded = false, opts_init = false, alloc_done = false;
+    bool stepped = false;            // wk.einfo is valid
     bool have_vecs = false;          // wk.Vt holds the eigenvectors of the previous step (warm start)
     int warm_run = 0;                // consecutive warm-started solves (a cold solve every 64 re-orthogonalises V)
     int warm_enabled = 1;
@@ -347,6 +348,7 @@ extern "C" int mopt_band_get_state(mopt_band *b, int image, mopt_rsirfo_state *o
     mopt_ctx *ctx = b->ctx;
     MOPT_HIP_TRY(ctx, hipMemcpyAsync(out, b->wk.states + loc, sizeof(mopt_rsirfo_state), hipMemcpyDeviceToHost, ctx->stream));
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (out->jacobi_sweeps < 0) { ctx->err = "mopt_band_get_state: the eigen-solver failed for this image"; return MOPT_E_NUMERIC; }
     return MOPT_OK;
 }
 
@@ -437,6 +439,7 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
     int rc = mopt_rsirfo_pipeline(ctx, wk, n, count, have_prev, false, nullptr, wk.H, warm);
     b->warm_run = warm ? b->warm_run + 1 : 0;
     b->have_vecs = true;
+    b->stepped = true;
     wk.x = sx; wk.bg = sbg; wk.g = sg; wk.px = spx; wk.pg = spg;
     if (rc != MOPT_OK) return rc;
     // 4.-7. step limit, TR_calc, FIRE, blend
@@ -458,7 +461,11 @@ extern "C" int mopt_band_download(mopt_band *b, double *newX_angstrom, double *F
     if (newX_angstrom) MOPT_HIP_TRY(ctx, hipMemcpyAsync(newX_angstrom, b->newX, cv, hipMemcpyDeviceToHost, ctx->stream));
     if (F) MOPT_HIP_TRY(ctx, hipMemcpyAsync(F, b->F, (size_t)b->I * b->n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (rfo_step) MOPT_HIP_TRY(ctx, hipMemcpyAsync(rfo_step, b->rfo_delta, cv, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int> einfo((size_t)2 * b->count, 0);
+    if (b->stepped) MOPT_HIP_TRY(ctx, hipMemcpyAsync(einfo.data(), b->wk.einfo, einfo.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < b->count; ++i)
+        if (einfo[2 * i + 1] & 4) { ctx->err = "mopt_band_download: the eigen-solver failed for an image of this shard"; return MOPT_E_NUMERIC; }
     return MOPT_OK;
 }
 

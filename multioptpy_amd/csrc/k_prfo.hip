@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(64) k_prfo_scalar(int n, const mopt_rsprfo_par
         st.micro_converged = converged ? 1 : 0;
         st.n_max = nmax;
         st.step_norm = sn;
-        st.jacobi_sweeps = einfo[0];
+        st.jacobi_sweeps = (einfo[1] & 4) ? -1 : einfo[0];
         st.iter += 1;
         state[0] = st;
         ts_row_out[0] = (p.saddle_order > 0 && p.mode_following_enabled && st.ts_mode_idx >= 0) ? vidx[st.ts_mode_idx] : -1;
@@ -376,7 +376,7 @@ extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *p
         if (hc.applied) {
             bool accept = true;
             if (!(sig / 1.0625 <= 1e6)) {
-                PTRY(mopt_launch_eigh(ctx, n, 1, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, false));
+                PTRY(mopt_eigh_auto(ctx, wk, n, 1, false));
                 std::vector<double> ev(n);
                 PD2H(ev.data(), wk.eigw, nv);
                 MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -396,7 +396,7 @@ extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *p
     hipLaunchKernelGGL(k_set_gnorm, dim3(1), dim3(1), 0, ctx->stream, dst.as<mopt_rsprfo_state>(), dgn.as<double>());
     // ---- 4. eigh(H + bias), not TR/rot projected (rsprfo.py:780-783)
     PTRY(mopt_launch_sym_add(ctx, n, 1, wk.H, wk.Bias, wk.A));
-    PTRY(mopt_launch_eigh(ctx, n, 1, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, false));
+    PTRY(mopt_eigh_auto(ctx, wk, n, 1, false));
     // ---- 5. g~ = V^T g, overlaps with the tracked TS vector, scalar logic, back-transformation
     const int have_ts = (ts_vec != nullptr && st.ts_mode_idx >= 0) ? 1 : 0;
     if (have_ts) PH2D(dts.p, ts_vec, nv);

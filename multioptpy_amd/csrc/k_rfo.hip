@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     st.initial_step_norm = rr.initial_norm;
     st.secular_iters = rr.secular_iters0;
     st.gradient_norm = gnorm;
-    st.jacobi_sweeps = einfo[2 * b];
+    st.jacobi_sweeps = (einfo[2 * b + 1] & 4) ? -1 : einfo[2 * b];       // -1: solver failure, surfaced as MOPT_E_NUMERIC
     st.hess_updated = coef ? coef[b].applied : 0;
     if (lane == 0) states[b] = st;
 }

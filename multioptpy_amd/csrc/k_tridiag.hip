@@ -264,6 +264,10 @@ __device__ __forceinline__ void ll_put(u64 *p, double v, unsigned tag) {
 __device__ __forceinline__ u64 ll_ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double ll_val(u64 a, u64 c) { return __longlong_as_double((long long)((a & 0xffffffffull) | (c << 32))); }
 constexpr unsigned LL_SPIN_LIMIT = 2000000u;
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for the fabric
+// acknowledgement of every write-through store still in flight (1-2 us each step here); the exchange words need no such
+// ordering because each carries its own tag.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // thread layout: cols = roundup64(n) column threads x RG row groups (wave-uniform); one column per thread (n <= 1024)
 __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap, int cols, int RG, double *__restrict__ A_,
@@ -271,14 +275,14 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
                                                       u64 *__restrict__ XCH_, size_t xch_stride, int *__restrict__ fail_,
                                                       long long *__restrict__ prof) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double red[2 * 16];
+    __shared__ double red[64];
     __shared__ int s_fail;
-    long long t_poll = 0, t_pro = 0, t_main = 0, t0 = 0, t1 = 0;
+    long long t_poll = 0, t_pro = 0, t_main = 0, t_loop = 0, t_bar = 0, t0 = 0, t1 = 0;
     double *sva = sm, *sw = sm + n, *svb = sm + 2 * n;      // reflector ping-pong (sva/svb), w
     double *accp = sm + 3 * n;                              // [RG][n] partial SYMV per row group
     double *Aloc = sm + (size_t)(3 + RG) * n;               // [rows_cap][n] rows owned by this workgroup
     const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
-    const int j = tid % cols, rg = tid / cols;
+    const int j = tid % cols, rg = __builtin_amdgcn_readfirstlane(tid / cols);
     double *A = A_ + (size_t)b * n * n;
     double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
     u64 *PARTX = XCH_ + (size_t)b * xch_stride;             // [2][G][n][2]
@@ -294,6 +298,8 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
     if (g == 0 && rg == 0 && j < n) ll_put(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u);
     double tau = 0.0, taun = 0.0;
     double *sv = sva, *svn = svb;
+    int r_end = 0;                                              // local rows that exist (global index < n)
+    for (int r = 0; r < rows_cap; ++r) r_end += ((g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC) < n) ? 1 : 0;
     for (int k = -1; k <= n - 3; ++k) {
         const int lo = k + 1, cur = k & 1, nxt = cur ^ 1;
         const int nk = k + 1;
@@ -341,35 +347,44 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
                 rowj = ll_val(a, c);
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (s_fail) break;
         if (prof) { t1 = wall_clock64(); t_poll += t1 - t0; t0 = t1; }
-        // ---- w_k
+        // ---- w_k = p + c v  (p = tau A v, c = -tau/2 p.v).  Reductions go through the two alternating halves of red[]:
+        // slot [w] = wave partial, slot [16] / [17] = single values other threads need (p_lo; alpha and the diagonal).
+        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, nw0 = cols >> 6;      // only the nw0 waves of row group 0 carry columns
+        const bool mine = (rg == 0 && j >= lo && j < n);
+        double wj_own = 0.0, w_lo = 0.0;
+        const double v_own = mine ? sv[j] : 0.0;
         if (k >= 0) {
-            double pv = 0.0;
-            const bool mine = (rg == 0 && j >= lo && j < n);
             const double pj = tau * psum;
-            if (mine) { sw[j] = pj; pv = pj * sv[j]; }
-            pv = block_sum1(pv, red);
+            const double pvw = wave_sum(mine ? pj * v_own : 0.0);
+            if (rg == 0 && lane == 0) red[wid] = pvw;
+            if (mine && j == lo) red[16] = pj;
+            lds_barrier();
+            double pv = 0.0;
+            for (int w = 0; w < nw0; ++w) pv += red[w];
             const double c = -0.5 * tau * pv;
-            if (mine) sw[j] = pj + c * sv[j];
-            __syncthreads();
+            wj_own = pj + c * v_own;
+            w_lo = red[16] + c * sv[lo];
+            if (mine) sw[j] = wj_own;
         }
         // ---- reflector of step k+1 from the updated row lo
         double betan = 0.0;
         taun = 0.0;
         if (build) {
-            double part = 0.0;
-            if (rg == 0 && j >= lo && j < n) {
-                double r = rowj;
-                if (k >= 0 && tau != 0.0) r -= sv[lo] * sw[j] + sw[lo] * sv[j];
-                svn[j] = r;
-                if (j >= lo + 2) part = r * r;
-            }
-            const double xn2 = block_sum1(part, red);
-            __syncthreads();
-            const double alpha = (lo + 1 < n) ? svn[lo + 1] : 0.0;
-            const double diag = svn[lo];
+            double r = rowj;
+            if (mine && k >= 0 && tau != 0.0) r -= sv[lo] * wj_own + w_lo * v_own;
+            const double xw = wave_sum((mine && j >= lo + 2) ? r * r : 0.0);
+            double *red2 = red + 32;
+            if (rg == 0 && lane == 0) red2[wid] = xw;
+            if (mine && j == lo + 1) red2[16] = r;
+            if (mine && j == lo) red2[17] = r;
+            lds_barrier();
+            double xn2 = 0.0;
+            for (int w = 0; w < nw0; ++w) xn2 += red2[w];
+            const double alpha = (lo + 1 < n) ? red2[16] : 0.0;
+            const double diag = red2[17];
             const double xnorm = sqrt(xn2);
             double scal = 0.0;
             betan = alpha;
@@ -378,31 +393,71 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
                 taun = (betan - alpha) / betan;
                 scal = 1.0 / (alpha - betan);
             }
-            __syncthreads();
-            if (rg == 0 && j >= lo && j < n) svn[j] = (j == lo) ? 0.0 : (j == lo + 1) ? 1.0 : svn[j] * scal;
-            __syncthreads();
+            if (mine) svn[j] = (j == lo) ? 0.0 : (j == lo + 1) ? 1.0 : r * scal;
             if (g == 0 && tid == 0) { D[nk] = diag; E[nk] = betan; TAU[nk] = taun; if (nk == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; } }
         }
+        lds_barrier();                                      // sw, svn complete
         if (k >= 0 && g == 0 && rg == RG - 1 && j >= k + 2 && j < n) A[(size_t)k * n + j] = sv[j];   // reflector k, dsytrd layout
-        // ---- main pass over the rows kept in LDS: rank-2 update with (v, w), next SYMV with v'
+        // ---- main pass over the rows kept in LDS: rank-2 update with (v, w), next SYMV with v'.
+        // Row group rg takes local rows rg, rg + RG, ...; the per-row scalars v_i, w_i, v'_i are fetched once per wave into
+        // lanes (lane q <-> q-th row of the group) and broadcast by v_readlane, so the inner loop is one LDS load and one store.
         const bool do_upd = (k >= 0 && tau != 0.0);
         const bool do_mv = build && (taun != 0.0);
         if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
         double acc = 0.0;
-        if (j > lo && j < n) {
-            const double wj = do_upd ? sw[j] : 0.0, vj = do_upd ? sv[j] : 0.0;
-            for (int r = rg; r < rows_cap; r += RG) {
-                const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
-                if (gi <= lo || gi >= n) continue;
-                double a = Aloc[(size_t)r * n + j];
-                if (do_upd) { a -= sv[gi] * wj + sw[gi] * vj; Aloc[(size_t)r * n + j] = a; }
-                if (do_mv) acc += a * svn[gi];
-                if (gi == lo + 1) ll_put(&ROWn[(size_t)j * 2], a, tag + 1u);       // (only the owner holds this row)
+        {
+            const bool colive = (j > lo && j < n);
+            const int jc = colive ? j : 0;
+            const double wj = do_upd ? sw[jc] : 0.0, vj = do_upd ? sv[jc] : 0.0;
+            // live local rows are r_first .. r_end - 1 (local order = global order); they are re-dealt over the row groups
+            // every step: group rg takes r_first + rg + t RG
+            const int m = (lo + 1) / TRI_RC, sft = (lo + 1) % TRI_RC;
+            int r_first;
+            if (m >= g && (m - g) % G == 0) r_first = ((m - g) / G) * TRI_RC + sft;
+            else r_first = (m < g) ? 0 : ((m - g + G - 1) / G) * TRI_RC;
+            const bool own_next = (m >= g && (m - g) % G == 0);            // this workgroup holds global row lo + 1 (= r_first)
+            const int cnt = (r_end - r_first - rg + RG - 1) / RG;           // may be <= 0
+            double *Ac = Aloc + jc;
+            for (int tb = 0; tb < cnt; tb += 64) {
+                const int t = tb + lane;
+                int gi_l = 0;
+                const bool rl = (t < cnt);
+                if (rl) { const int r = r_first + rg + t * RG; gi_l = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC); }
+                const double xs = rl ? sv[gi_l] : 0.0, ws = rl ? sw[gi_l] : 0.0, zs = rl ? svn[gi_l] : 0.0;
+                const int tcnt = (cnt - tb < 64) ? cnt - tb : 64;
+                int q = 0;
+                for (; q + 4 <= tcnt; q += 4) {
+                    double a[4];
+                    const int r0 = r_first + rg + (tb + q) * RG;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) a[u] = Ac[(size_t)(r0 + u * RG) * n];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double vi = lane_bcast(xs, q + u), wi = lane_bcast(ws, q + u), zi = lane_bcast(zs, q + u);
+                        if (do_upd) a[u] -= vi * wj + wi * vj;
+                        if (do_mv) acc += a[u] * zi;
+                    }
+                    if (do_upd && colive) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) Ac[(size_t)(r0 + u * RG) * n] = a[u];
+                    }
+                }
+                for (; q < tcnt; ++q) {
+                    const int r = r_first + rg + (tb + q) * RG;
+                    const double vi = lane_bcast(xs, q), wi = lane_bcast(ws, q), zi = lane_bcast(zs, q);
+                    double a0 = Ac[(size_t)r * n];
+                    if (do_upd) { a0 -= vi * wj + wi * vj; if (colive) Ac[(size_t)r * n] = a0; }
+                    if (do_mv) acc += a0 * zi;
+                }
             }
+            if (own_next && rg == 0 && colive && r_first < r_end) ll_put(&ROWn[(size_t)j * 2], Ac[(size_t)r_first * n], tag + 1u);
+            if (!colive) acc = 0.0;
         }
+        if (prof) { t1 = wall_clock64(); t_loop += t1 - t0; t0 = t1; }
         if (RG > 1) {
             if (j < n) accp[(size_t)rg * n + j] = acc;
-            __syncthreads();
+            lds_barrier();
+            if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
             if (rg == 0 && j < n) {
                 acc = 0.0;
                 for (int q = 0; q < RG; ++q) acc += accp[(size_t)q * n + j];
@@ -411,10 +466,10 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         if (rg == 0 && j > lo && j < n) ll_put(&PARTn[((size_t)g * n + j) * 2], acc, tag + 1u);
         tau = taun;
         { double *t = sv; sv = svn; svn = t; }
-        __syncthreads();
+        if (RG == 1) lds_barrier();                         // (with RG > 1 the accp barrier already separates the steps)
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
     }
-    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 4; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; }
+    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; }
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
     // D[n-1]: owner of the last row
     {
@@ -780,7 +835,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
         const int rows = rows_for(G);
         long long *d_prof = nullptr;
-        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 32); hipMemset(d_prof, 0, (size_t)batch * G * 32); }
+        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
         // exchange words live at the head of each matrix' slot of d_Vt (free until k_tri_invit): (4 G + 4) n 64-bit words <= n^2
         const size_t xwords = ((size_t)4 * G + 4) * n;
@@ -789,17 +844,17 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             const int nb_ = (batch - b0 < per) ? batch - b0 : per;
             hipLaunchKernelGGL(k_tri_persist, dim3(G, nb_), dim3(cols * RG), lds_for(G), ctx->stream, n, G, rows, cols, RG,
                                d_A + (size_t)b0 * n * n, d_D + (size_t)b0 * n, d_E + (size_t)b0 * n, d_TAU + (size_t)b0 * n,
-                               (u64 *)(d_Vt + (size_t)b0 * n * n), (size_t)n * n, d_fail + b0, d_prof ? d_prof + (size_t)b0 * G * 4 : nullptr);
+                               (u64 *)(d_Vt + (size_t)b0 * n * n), (size_t)n * n, d_fail + b0, d_prof ? d_prof + (size_t)b0 * G * 8 : nullptr);
         }
         if (d_prof) {
-            std::vector<long long> h((size_t)batch * G * 4);
+            std::vector<long long> h((size_t)batch * G * 8);
             hipStreamSynchronize(ctx->stream);
             hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
             hipFree(d_prof);
-            double sp = 0, sr = 0, smn = 0;
-            for (int i = 0; i < batch * G; ++i) { sp += h[4 * i]; sr += h[4 * i + 1]; smn += h[4 * i + 2]; }
+            double sp = 0, sr = 0, smn = 0, sl = 0, sb = 0;
+            for (int i = 0; i < batch * G; ++i) { sp += h[8 * i]; sr += h[8 * i + 1]; smn += h[8 * i + 2]; sl += h[8 * i + 3]; sb += h[8 * i + 4]; }
             const double f = 0.01 / (batch * G) / (n - 1);     // 100 MHz ticks -> us per step
-            fprintf(stderr, "[tri_prof] n=%d G=%d RG=%d per step: poll %.2f us, prologue %.2f us, main %.2f us\n", n, G, RG, sp * f, sr * f, smn * f);
+            fprintf(stderr, "[tri_prof] n=%d G=%d RG=%d per step: poll %.2f us, prologue %.2f us, loop %.2f us, barrier %.2f us, tail %.2f us\n", n, G, RG, sp * f, sr * f, sl * f, sb * f, smn * f);
         }
     } else if (multi) {
         mopt_scope sc(ctx, "eigh_tridiag", n);
@@ -835,6 +890,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         else BT(24);
 #undef BT
     }
+    if (getenv("MOPT_TRI_INJECT_FAIL")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 1, sizeof(int), ctx->stream));   // test hook: matrix 0 fails
     {
         mopt_scope sc(ctx, "eigh_final", 1);
         int np2 = 1;

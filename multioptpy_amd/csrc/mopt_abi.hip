@@ -159,7 +159,7 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     TRY(dsig.alloc(ctx, batch * sizeof(double))); TRY(drot.alloc(ctx, (size_t)batch * (JAC_MAX_SWEEPS + 1) * sizeof(int)));
     TRY(dW.alloc(ctx, nv)); TRY(dperm.alloc(ctx, (size_t)batch * n * sizeof(int))); TRY(dinfo.alloc(ctx, (size_t)batch * 2 * sizeof(int)));
     H2D(ctx, dA.p, A, nn);
-    if (mopt_eigh_algo() == 1 && n >= 3) {
+    if (mopt_eigh_algo(n) == 1) {
         DBuf dsc, dsi;
         const size_t nvi = (size_t)batch * n;
         TRY(dsc.alloc(ctx, 5 * nvi * 8)); TRY(dsi.alloc(ctx, (3 * nvi + 2 * batch) * 4));
@@ -177,6 +177,8 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     D2H(ctx, info.data(), dinfo.p, (size_t)batch * 2 * sizeof(int));
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (sweeps_out) for (int b = 0; b < batch; ++b) sweeps_out[b] = info[2 * b];
+    for (int b = 0; b < batch; ++b)
+        if (info[2 * b + 1] & 4) { ctx->err = "mopt_eigh: the reduction-route eigen-solver failed (inverse iteration or workgroup hand-off)"; return MOPT_E_NUMERIC; }
     return MOPT_OK;
 }
 
@@ -271,5 +273,7 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
     if (H_sym) D2H(ctx, H_sym, wk.H, nn);
     if (H_inplace) D2H(ctx, H_inplace, any_upd ? wk.Hinpl : wk.H, nn);
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < batch; ++b)
+        if (state[b].jacobi_sweeps < 0) { ctx->err = "mopt_rsirfo_run: the eigen-solver failed"; return MOPT_E_NUMERIC; }
     return MOPT_OK;
 }

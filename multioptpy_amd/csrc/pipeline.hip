@@ -61,25 +61,32 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     if (rc != MOPT_OK) return rc;
     rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A);
     if (rc != MOPT_OK) return rc;
-    if (mopt_eigh_algo() == 1 && n >= 3) {
-        // reduction route: work on a copy (the reflectors overwrite it), eigenvectors land in Vt
-        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.Gt, wk.A, (size_t)batch * n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-        rc = mopt_launch_eigh_tridiag(ctx, n, batch, wk.Gt, wk.Vt, wk.tri.D, wk.tri.E, wk.tri.TAU, wk.tri.WT, wk.tri.onenrm, wk.tri.bstart,
-                                      wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo);
-    } else {
-        rc = mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm_eigh);
-    }
+    rc = mopt_eigh_auto(ctx, wk, n, batch, warm_eigh);
     if (rc != MOPT_OK) return rc;
     rc = mopt_launch_rfo(ctx, n, batch, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, wk.gp, wk.bg, wk.be, coef,
                          wk.gt_all, wk.coefout, wk.step);
     return rc;
 }
 
-int mopt_eigh_algo() {
-    static int algo = -1;
-    if (algo < 0) {
-        const char *e = getenv("MOPT_EIGH_ALGO");
-        algo = (e && (e[0] == 't' || e[0] == '1')) ? 1 : 0;
+// eigh(wk.A) -> wk.eigw (ascending through wk.perm), wk.Vt (vector-major), wk.einfo; wk.A is preserved
+int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm) {
+    if (mopt_eigh_algo(n) == 1) {
+        // reduction route: work on a copy (the reflectors overwrite it), eigenvectors land in Vt
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.Gt, wk.A, (size_t)batch * n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+        return mopt_launch_eigh_tridiag(ctx, n, batch, wk.Gt, wk.Vt, wk.tri.D, wk.tri.E, wk.tri.TAU, wk.tri.WT, wk.tri.onenrm, wk.tri.bstart,
+                                        wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo);
     }
-    return algo;
+    return mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm);
+}
+
+// Default: reduction route from n = 32 on (the Jacobi sweeps are cheaper below that and need no deflation logic);
+// MOPT_EIGH_ALGO=jacobi / tridiag forces one route for every size (tridiag needs n >= 3).
+int mopt_eigh_algo(int n) {
+    static int algo = -2;
+    if (algo == -2) {
+        const char *e = getenv("MOPT_EIGH_ALGO");
+        algo = !e ? -1 : (e[0] == 't' || e[0] == '1') ? 1 : 0;
+    }
+    if (n < 3) return 0;
+    return algo >= 0 ? algo : (n >= 32 ? 1 : 0);
 }

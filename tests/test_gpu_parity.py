@@ -339,8 +339,10 @@ def test_rsprfo_traces_vs_reference():
     print("RSPRFO worst step deviation from the reference:", worst)
 
 
-def test_eigh_reduction_route(ops):
-    """The tridiagonal-reduction eigen-solver (MOPT_EIGH_ALGO=tridiag): random, degenerate, clustered and LJ matrices."""
+@pytest.mark.parametrize("algo", ["tridiag", "jacobi"])
+def test_eigh_forced_route(ops, algo):
+    """Both eigen-solvers forced for every size (MOPT_EIGH_ALGO): random, degenerate, clustered and LJ matrices.
+    (By default the reduction route runs from n = 32 on and the Jacobi sweeps below.)"""
     import subprocess
     import sys
     code = r'''
@@ -376,8 +378,45 @@ for b in range(3):
     assert np.abs(w[b] - np.linalg.eigvalsh(B[b])).max() < 1e-13 * max(1.0, np.abs(B[b]).sum(axis=1).max())
 sys.exit(bad)
 '''
-    env = dict(os.environ, MOPT_EIGH_ALGO="tridiag")
+    env = dict(os.environ, MOPT_EIGH_ALGO=algo)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     print(r.stdout)
     print(r.stderr[-2000:])
+    assert r.returncode == 0
+
+
+@pytest.mark.parametrize("algo", ["tridiag", "jacobi"])
+def test_traces_forced_route(algo):
+    """The RSIRFO traces (G2), the band steps (G7) and the RS-P-RFO traces (G3) with one eigen-solver forced for every size."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MOPT_EIGH_ALGO=algo)
+    root = os.path.dirname(os.path.dirname(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-q", "-x", "-m", "gpu", "-k",
+                        "(rsirfo or band or rsprfo or shard) and not forced"], env=env, capture_output=True, text=True, cwd=root)
+    print(r.stdout[-3000:])
+    print(r.stderr[-2000:])
+    assert r.returncode == 0
+
+
+def test_eigensolver_failure_is_loud():
+    """A failure flag from the reduction route (injected) must surface as MOPT_E_NUMERIC / MoptError, never as a silent result."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from multioptpy_amd import ops
+from multioptpy_amd._lib import MoptError
+R = np.random.default_rng(0).normal(size=(2, 40, 40)); A = R + R.transpose(0, 2, 1)
+try:
+    ops.eigh(A)
+except MoptError as e:
+    assert "-5" in str(e), str(e)
+    sys.exit(0)
+sys.exit(1)
+'''
+    env = dict(os.environ, MOPT_EIGH_ALGO="tridiag", MOPT_TRI_INJECT_FAIL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
+    print(r.stdout, r.stderr[-2000:])
     assert r.returncode == 0
