@@ -194,9 +194,18 @@ def main():
         ach = bytes_dom / t_dom / 1e9 if t_dom > 0 else 0.0
         flops_step = ((20.0 / 3.0) * n ** 3 + 40.0 * n * n) * count
         step_kernel_ms = sum(v["ms_per_step"] for v in fam.values())
+        traffic = None
+        try:    # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_bench.sh)
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as fh:
+                tj = json.load(fh).get(kname)
+            if tj and I == 32 and N == 100 and world == 1:
+                traffic = (tj["fetch_kb_per_launch"] + tj["write_kb_per_launch"]) * 1024.0
+        except (OSError, ValueError, KeyError):
+            traffic = None
         roofline = {
             "bound": "hbm", "kernel": kname,
-            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), bytes",
             "alg_bytes_per_step_dominant": bytes_dom, "kernel_ms_per_step": fam[dom]["ms_per_step"],
             "launches_per_step": fam[dom]["launches_per_step"],
             "whole_step": {"alg_bytes": 80.0 * n * n * count, "alg_flops": flops_step, "kernel_ms": step_kernel_ms,
