@@ -93,6 +93,23 @@ int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, double *W, doubl
  * rsirfo.py:423,927,940; used internally to warm-start the eigen-solver from the previous eigenvectors). */
 int mopt_dgemm(mopt_ctx *ctx, int n, int batch, const double *A, const double *B, double *C);
 
+/* ---- callers around the step: CalculateMoveVector / TrustRadius / Kabsch ------------------ */
+
+/* TrustRadius.update_trust_radii's predicted energy change (multioptpy/Optimizer/trust_radius.py:146-151):
+ * out[b] = g_b . s_b + 1/2 s_b^T H_b s_b for batch x n x n Hessians. */
+int mopt_quadratic_model(mopt_ctx *ctx, int n, int batch, const double *H, const double *g, const double *s, double *out);
+
+/* CalculateMoveVector.calc_move_vector, the part after optimizer.run (multioptpy/optimizer.py:789-812):
+ * if ||step|| > trust_radius: step = trust_radius * step / ||step||;  new_geometry = (x - step) * bohr2ang (angstrom),
+ * move_vector = step (bohr).  n = 3N values each; step_norm (may be NULL) = ||step|| before clipping. */
+int mopt_clip_and_move(mopt_ctx *ctx, int n, const double *x_bohr, const double *step, double trust_radius, double bohr2ang,
+                       double *new_geometry_ang, double *move_vector, double *step_norm);
+
+/* Calculationtools.kabsch_algorithm (multioptpy/Utils/calc_tools.py:412-425) for N x 3 arrays: both centred on their
+ * centroids (the reference does that IN PLACE on its arguments; here the centred Q is returned in Q_centred), proper
+ * rotation from the 3 x 3 SVD, P_aligned = (R P_centred^T)^T. */
+int mopt_kabsch(mopt_ctx *ctx, int N, const double *P, const double *Q, double *P_aligned, double *Q_centred);
+
 /* ---- RSIRFO.run (multioptpy/Optimizer/rsirfo.py:285-490), batched ---------------------- */
 
 typedef struct mopt_rsirfo_params {

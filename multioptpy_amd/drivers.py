@@ -1,0 +1,131 @@
+"""In-memory counterparts of the reference's iteration loops: the harness that owns the
+Calculator call and feeds the device-backed optimizer step.  No files: the reference's per-iteration XYZ round trip
+(`%17.12f` angstrom, fileio.py:442-446) is kept as a quantisation of the geometry so that trajectories stay comparable
+with the reference's (switch it off with quantise=False).
+
+`optmain_steps` follows multioptpy/optimization.py:1780-2092 for the unbiased, unconstrained, all-active case:
+  compute E, g -> Hessian hand-over with the reference's aliasing (set_bias_hessian / set_hessian) -> calc_move_vector
+  -> Kabsch onto the current geometry (which centres it in place) -> displacement -> 4-criterion convergence test with
+  force-adaptive displacement thresholds -> shift "previous" state.
+The Calculator is any object with the reference's plugin interface:
+  single_point(file_directory, element_number_list, iter, [charge, mult], method, geom_num_list=<angstrom (N,3)>)
+      -> (energy [hartree], gradient (N,3) [hartree/bohr], geometry (N,3) [bohr], finish_flag)
+  and the attribute Model_hess (the Hessian hand-over of lj_calculation_tools.py:195-207, tblite_calculation_tools.py)."""
+import copy
+
+import numpy as np
+
+from .optimizer import CalculateMoveVector, BOHR2ANGSTROMS
+from .Utils.calc_tools import Calculationtools
+
+
+def quantise_xyz(x_ang):
+    return np.array([[float(f"{v:>17.12f}") for v in row] for row in np.asarray(x_ang)], dtype="float64")
+
+
+def calculate_rms_safely(vector, threshold=1e-10):
+    """optimization.py:1246-1252."""
+    filtered = vector[np.abs(vector) > threshold]
+    return float(np.sqrt((filtered ** 2).mean())) if filtered.size > 0 else 0.0
+
+
+class ConvergenceChecker:
+    """optimization.py:1254-1289; default thresholds optimization.py:129-132."""
+
+    def __init__(self, max_force=3e-4, rms_force=2e-4, max_displacement=1.5e-3, rms_displacement=1e-3):
+        self.MAX_FORCE_THRESHOLD = max_force
+        self.RMS_FORCE_THRESHOLD = rms_force
+        self.MAX_DISPLACEMENT_THRESHOLD = max_displacement
+        self.RMS_DISPLACEMENT_THRESHOLD = rms_displacement
+
+    def check_convergence(self, effective_gradient, displacement_vector, optimizer_instances):
+        max_force = np.abs(effective_gradient).max()
+        rms_force = calculate_rms_safely(effective_gradient)
+        delta_max = max(0.0, self.MAX_FORCE_THRESHOLD - 1 * max_force)
+        delta_rms = max(0.0, self.RMS_FORCE_THRESHOLD - 1 * rms_force)
+        max_displacement = np.abs(displacement_vector).max()
+        rms_displacement = calculate_rms_safely(displacement_vector)
+        max_th = max(self.MAX_DISPLACEMENT_THRESHOLD, self.MAX_DISPLACEMENT_THRESHOLD + delta_max)
+        rms_th = max(self.RMS_DISPLACEMENT_THRESHOLD, self.RMS_DISPLACEMENT_THRESHOLD + delta_rms)
+        if (max_force < self.MAX_FORCE_THRESHOLD and rms_force < self.RMS_FORCE_THRESHOLD
+                and max_displacement < max_th and rms_displacement < rms_th):
+            return True, max_th, rms_th
+        for opt in optimizer_instances:
+            if getattr(opt, "proj_grad_converged", False):
+                return True, max_th, rms_th
+        return False, max_th, rms_th
+
+
+def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, saddle_order=0, NSTEP=300, FC_COUNT=-1,
+                  max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False):
+    """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy)."""
+    natom = len(element_list)
+    geometry = np.array(start_geometry_ang, dtype="float64") / BOHR2ANGSTROMS
+    initial_geometry = copy.deepcopy(geometry)
+    pre_geometry = np.zeros((natom, 3))
+    pre_bias_gradient = np.zeros((natom, 3))
+    pre_raw_gradient = np.zeros((natom, 3))
+    pre_move_vector = np.zeros((natom, 3))
+    pre_bias_energy = 0.0
+    Model_hess = np.eye(natom * 3)
+    CMV = CalculateMoveVector("x", element_list, saddle_order, FC_COUNT, 0.0, None, max_trust_radius=max_trust_radius,
+                              min_trust_radius=min_trust_radius)
+    methods = opt_method if isinstance(opt_method, (list, tuple)) else [opt_method]
+    optimizer_instances = CMV.initialization(list(methods))
+    for opt in optimizer_instances:
+        opt.set_hessian(Model_hess)
+    convergence = ConvergenceChecker()
+    tools = Calculationtools()
+    converged = False
+    energy = None
+    it = -1
+    for it in range(NSTEP):
+        # StandardHandler.compute (optimization.py:318-343)
+        x_ang = geometry * BOHR2ANGSTROMS
+        if quantise:
+            x_ang = quantise_xyz(x_ang)
+        calculator.Model_hess = copy.deepcopy(Model_hess)
+        e, g, geom_bohr, exit_flag = calculator.single_point(None, None, it, [0, 1], getattr(calculator, "xtb_method", ""),
+                                                             geom_num_list=x_ang)
+        if exit_flag:
+            break
+        geometry = np.array(geom_bohr, dtype="float64")
+        Model_hess = copy.deepcopy(calculator.Model_hess)
+        energy = e
+        bias_hessian = np.zeros((3 * natom, 3 * natom))
+        if it == 0:                                                     # _save_init_geometry (optimization.py:2206-2217)
+            centre = tools.calc_center(geometry, element_list)
+            pre_geometry = (geometry - centre) - centre
+        # HessianManager.calc_eff_hess_for_fix_atoms_and_set_hess (optimization.py:1311-1365), all atoms active
+        for inst in optimizer_instances:
+            inst.set_bias_hessian(bias_hessian)
+            if it % FC_COUNT == 0:
+                inst.set_hessian(Model_hess)
+        g_raw = copy.deepcopy(np.asarray(g, dtype="float64"))
+        B_g = copy.deepcopy(np.asarray(g, dtype="float64"))
+        effective_gradient = g_raw + (B_g - g_raw)
+        geometry_in = geometry.copy() if record is not None else None
+        new_geometry, move_vector, optimizer_instances = CMV.calc_move_vector(
+            it, geometry, B_g, pre_bias_gradient, pre_geometry, e, pre_bias_energy, pre_move_vector, initial_geometry, g_raw,
+            pre_raw_gradient, optimizer_instances, False, print_flag)
+        new_raw = new_geometry.copy() if record is not None else None
+        # ConstraintManager.project_out_translation_rotation (optimization.py:1207-1213)
+        aligned, _ = tools.kabsch_algorithm(new_geometry / BOHR2ANGSTROMS, geometry)
+        new_geometry = aligned * BOHR2ANGSTROMS
+        displacement_vector = move_vector if it == 0 else new_geometry / BOHR2ANGSTROMS - geometry
+        converge_flag, max_th, rms_th = convergence.check_convergence(effective_gradient, displacement_vector, optimizer_instances)
+        if record is not None:
+            record.append(dict(geom=geometry_in, B_g=B_g.copy(), B_e=float(e), pre_B_e=float(pre_bias_energy), tr=float(CMV.trust_radii),
+                               new=new_raw, aligned=new_geometry.copy(), mv=move_vector.copy(),
+                               H=np.array(optimizer_instances[0].hessian, dtype="float64"),
+                               conv=(converge_flag, max_th, rms_th), disp=np.array(displacement_vector, dtype="float64")))
+        if converge_flag:
+            converged = True
+            break
+        pre_bias_energy = e
+        pre_bias_gradient = B_g
+        pre_raw_gradient = g_raw
+        pre_geometry = geometry
+        pre_move_vector = move_vector
+        geometry = new_geometry / BOHR2ANGSTROMS
+    return dict(converged=converged, iterations=it + 1, geometry_bohr=geometry, energy=energy)

@@ -101,3 +101,39 @@ def neb_force(variant, X, E, G, optimize_num=0, apply_ci_neb=99999):
     c = ctx()
     check(lib().mopt_neb_force(c, v, I, N, ptr(X), ptr(E), ptr(G), int(optimize_num), int(apply_ci_neb), ptr(F), None), c)
     return F
+
+
+def quadratic_model(H, g, s):
+    """g.s + 1/2 s^T H s (TrustRadius.update_trust_radii, trust_radius.py:146-151); H (n,n) or (B,n,n)."""
+    H = f64(H)
+    H3 = H.reshape((-1,) + H.shape[-2:])
+    B, n = H3.shape[0], H3.shape[1]
+    g = f64(g).reshape(B, n)
+    s = f64(s).reshape(B, n)
+    out = np.zeros(B)
+    c = ctx()
+    check(lib().mopt_quadratic_model(c, n, B, ptr(H3), ptr(g), ptr(s), ptr(out)), c)
+    return float(out[0]) if H.ndim == 2 else out
+
+
+def clip_and_move(x_bohr, step, trust_radius, bohr2ang):
+    """optimizer.py:789-812: returns (new_geometry [angstrom], move_vector [bohr], ||step|| before clipping), flat arrays."""
+    x = f64(x_bohr).reshape(-1)
+    st = f64(step).reshape(-1)
+    new = np.empty_like(x)
+    mv = np.empty_like(x)
+    nrm = np.zeros(1)
+    c = ctx()
+    check(lib().mopt_clip_and_move(c, x.size, ptr(x), ptr(st), float(trust_radius), float(bohr2ang), ptr(new), ptr(mv), ptr(nrm)), c)
+    return new, mv, float(nrm[0])
+
+
+def kabsch(P, Q):
+    """calc_tools.py:412-425 without the in-place side effects: returns (rotated centred P, centred Q), both (N,3)."""
+    P = f64(P).reshape(-1, 3)
+    Q = f64(Q).reshape(-1, 3)
+    Pa = np.empty_like(P)
+    Qc = np.empty_like(Q)
+    c = ctx()
+    check(lib().mopt_kabsch(c, P.shape[0], ptr(P), ptr(Q), ptr(Pa), ptr(Qc)), c)
+    return Pa, Qc

@@ -1,0 +1,165 @@
+"""Drop-in for multioptpy/optimizer.py::CalculateMoveVector restricted to the quasi-Newton methods of the hot path
+(rsirfo_* -> RSIRFO, rsprfo_* -> EnhancedRSPRFO).
+
+Same constructor, `initialization(method)` and `calc_move_vector(...)` signatures and return values as the reference
+(optimizer.py:259-307, 309-533, 740-818).  The step itself comes from the device-backed optimizer classes; the outer
+trust radius keeps its scalar logic on the host (Optimizer/trust_radius.py here) with the predicted energy change on the
+device; the clip + geometry update is mopt_clip_and_move.  Method strings that request the reference's step "enhancements"
+(lookahead, lars, *diis, linesearch, trim, ...) or non-Newton optimizers raise NotImplementedError: they are outside the
+path this package replaces."""
+import copy
+
+import numpy as np
+
+from . import ops
+from .Optimizer.rsirfo import RSIRFO
+from .Optimizer.rsprfo import EnhancedRSPRFO
+from .Optimizer.trust_radius import TrustRadius
+
+BOHR2ANGSTROMS = 0.52917721067          # Parameters/parameter.py:27
+
+_ENHANCEMENTS = ("lookahead", "lars", "linesearch", "gdiis", "kdiis", "adiis", "c2diis", "ediis", "coordinate_locking",
+                 "component_wise_scaling", "gpr_step", "gan_step", "rl_step", "geodesic_step", "trim")
+_OTHER_NEWTON = ("mf_rsirfo", "crsirfo")
+
+
+class CalculateMoveVector:
+    def __init__(self, DELTA, element_list, saddle_order=0, FC_COUNT=-1, temperature=0.0, model_hess_flag=None,
+                 max_trust_radius=None, min_trust_radius=None, **kwargs):
+        self.DELTA = DELTA
+        self.temperature = temperature
+        self.FC_COUNT = FC_COUNT
+        self.MAX_RMS_FORCE_SWITCHING_THRESHOLD = 0.05
+        self.MIN_RMS_FORCE_SWITCHING_THRESHOLD = 0.005
+        self.projection_constraint = kwargs.get("projection_constraint", None)
+        self.max_trust_radius = max_trust_radius
+        self.min_trust_radius = min_trust_radius
+        self.CALC_TRUST_RADII = TrustRadius()
+        if self.max_trust_radius is not None:
+            if self.max_trust_radius <= 0.0:
+                raise SystemExit("max_trust_radius must be greater than 0.0")
+            self.CALC_TRUST_RADII.set_max_trust_radius(self.max_trust_radius)
+        if self.max_trust_radius is None:
+            self.max_trust_radius = 0.1 if saddle_order > 0 else 0.5
+            self.trust_radii = self.max_trust_radius
+        else:
+            if saddle_order > 0:
+                self.trust_radii = min(self.max_trust_radius, 0.1)
+            else:
+                self.trust_radii = self.max_trust_radius if type(self.max_trust_radius) is float else 0.5
+        if self.min_trust_radius is not None:
+            if self.min_trust_radius <= 0.0:
+                raise SystemExit("min_trust_radius must be greater than 0.0")
+            if self.trust_radii < self.min_trust_radius:
+                self.trust_radius = self.min_trust_radius        # (sic, optimizer.py:297: a new attribute, no effect)
+            self.CALC_TRUST_RADII.set_min_trust_radius(self.min_trust_radius)
+        self.min_trust_radius = min_trust_radius if min_trust_radius is not None else 0.01
+        self.saddle_order = saddle_order
+        self.iter = 0
+        self.element_list = element_list
+        self.model_hess_flag = model_hess_flag
+        self.display_eigvals = False      # the reference prints the projected Hessian's eigenvalues every step (optimizer.py:822-841)
+        self.newton_tag = []
+
+    def initialization(self, method):
+        """optimizer.py:309-533 for the rsirfo / rsprfo families."""
+        optimizer_instances = []
+        self.newton_tag = []
+        for m in method:
+            low = m.lower()
+            if any(k in low for k in _ENHANCEMENTS) or any(k in low for k in _OTHER_NEWTON):
+                raise NotImplementedError(f"multioptpy_amd replaces the rsirfo_*/rsprfo_* step only, not '{m}'")
+            if "rsprfo" in low:
+                opt = EnhancedRSPRFO(method=m, saddle_order=self.saddle_order, element_list=self.element_list,
+                                     trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius)
+            elif "rsirfo" in low:
+                opt = RSIRFO(method=m, saddle_order=self.saddle_order, element_list=self.element_list,
+                             trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius)
+            else:
+                raise NotImplementedError(f"multioptpy_amd replaces the rsirfo_*/rsprfo_* step only, not '{m}'")
+            opt.DELTA = 0.50                                      # quasi_newton_mapping: every rsirfo/rsprfo key has delta 0.50
+            optimizer_instances.append(opt)
+            self.newton_tag.append(True)
+        return optimizer_instances
+
+    def update_trust_radius_conditionally(self, optimizer_instances, B_e, pre_B_e, pre_B_g, pre_move_vector, geom_num_list):
+        """optimizer.py:534-575."""
+        if self.FC_COUNT == -1 and not self.model_hess_flag is not None:      # noqa: E714  (the reference's own expression)
+            return
+        model_hess = None
+        for i in range(len(optimizer_instances)):
+            if self.newton_tag[i]:
+                model_hess = optimizer_instances[i].hessian + optimizer_instances[i].bias_hessian
+                break
+        if not (model_hess is None and self.FC_COUNT == -1) and True in self.newton_tag:
+            self.trust_radii = self.CALC_TRUST_RADII.update_trust_radii(B_e, pre_B_e, pre_B_g, pre_move_vector, model_hess,
+                                                                        geom_num_list, self.trust_radii)
+        if self.max_trust_radius is None:                          # unreachable after __init__, kept for fidelity (:561-569)
+            if self.saddle_order > 0:
+                self.trust_radii = min(self.trust_radii, 0.1)
+
+    def handle_projection_constraint(self, projection_constrain):
+        if projection_constrain and self.max_trust_radius is None:
+            self.trust_radii = min(self.trust_radii, 0.1)
+
+    def switch_move_vector(self, B_g, move_vector_list, method_list=None, max_rms_force_switching_threshold=0.05,
+                           min_rms_force_switching_threshold=0.005, steepness=10.0, offset=0.5):
+        """optimizer.py:590-625."""
+        if len(method_list) == 1:
+            return copy.copy(move_vector_list[0]), method_list
+        rms_force = abs(np.sqrt(np.square(B_g).mean()))
+        if rms_force > max_rms_force_switching_threshold:
+            return copy.copy(move_vector_list[0]), method_list
+        elif min_rms_force_switching_threshold < rms_force <= max_rms_force_switching_threshold:
+            x_j = (rms_force - min_rms_force_switching_threshold) / (max_rms_force_switching_threshold - min_rms_force_switching_threshold)
+            f_val = 1 / (1 + np.exp(-steepness * (x_j - offset)))
+            return (np.array(move_vector_list[0], dtype="float64") * f_val
+                    + np.array(move_vector_list[1], dtype="float64") * (1.0 - f_val)), method_list
+        return copy.copy(move_vector_list[1]), method_list
+
+    def calc_move_vector(self, iter, geom_num_list, B_g, pre_B_g, pre_geom, B_e, pre_B_e, pre_move_vector, initial_geom_num_list,
+                         g, pre_g, optimizer_instances, projection_constrain=False, print_flag=True):
+        """optimizer.py:740-818.  geom_num_list in bohr; returns (new_geometry [angstrom] (N,3), move_vector [bohr] (N,3),
+        optimizer_instances)."""
+        natom = len(geom_num_list)
+        geom_num_list = geom_num_list.reshape(natom * 3, 1)
+        B_g = B_g.reshape(natom * 3, 1)
+        pre_B_g = pre_B_g.reshape(natom * 3, 1)
+        pre_geom = pre_geom.reshape(natom * 3, 1)
+        g = g.reshape(natom * 3, 1)
+        pre_g = pre_g.reshape(natom * 3, 1)
+        pre_move_vector = pre_move_vector.reshape(natom * 3, 1)
+        initial_geom_num_list = initial_geom_num_list.reshape(natom * 3, 1)
+        self.iter = iter
+        self.geom_num_list = geom_num_list
+        self.update_trust_radius_conditionally(optimizer_instances, B_e, pre_B_e, pre_B_g, pre_move_vector, geom_num_list)
+        self.handle_projection_constraint(projection_constrain)
+        move_vector_list = []
+        for inst in optimizer_instances:
+            mv = inst.run(geom_num_list, B_g, pre_B_g, pre_geom, B_e, pre_B_e, pre_move_vector, initial_geom_num_list, g, pre_g)
+            move_vector_list.append(np.array(mv, dtype="float64"))
+        move_vector, optimizer_instances = self.switch_move_vector(B_g, move_vector_list, optimizer_instances)
+        new_geometry, move_vector, step_norm = ops.clip_and_move(geom_num_list, move_vector, self.trust_radii, BOHR2ANGSTROMS)
+        if print_flag:
+            print("==================================================================================")
+            print("trust radii (unit. ang.): ", self.trust_radii)
+            print("step  radii (unit. ang.): ", min(step_norm, self.trust_radii) if step_norm > self.trust_radii else step_norm)
+        new_geometry = new_geometry.reshape(natom, 3)
+        move_vector = move_vector.reshape(natom, 3)
+        if self.display_eigvals:
+            for i, inst in enumerate(optimizer_instances):
+                if self.newton_tag[i]:
+                    display_eigvals(inst.hessian, inst.bias_hessian, self.element_list, new_geometry / BOHR2ANGSTROMS)
+        return new_geometry, np.array(move_vector, dtype="float64"), optimizer_instances
+
+
+def display_eigvals(hessian, bias_hessian, element_list, geom):
+    """optimizer.py:822-841: eigenvalues of the TR/rot-projected Hessian (device projection + device eigen-solver)."""
+    H = hessian + bias_hessian if bias_hessian is not None else hessian
+    H = ops.project_hess(np.asarray(H, dtype="float64"), np.asarray(geom, dtype="float64").reshape(-1))
+    H = (H + H.T) / 2
+    evals, _ = ops.eigh(H)
+    vals = np.sort(evals[np.abs(evals) > 1e-10])
+    print(f"EIGENVALUES (NORMAL COORDINATE, NUMBER OF VALUES: {len(vals)}):")
+    for i in range(0, len(vals), 6):
+        print(' '.join(f'{v:12.8f}' for v in vals[i:i + 6]))

@@ -35,8 +35,11 @@ def band(I, N):
     return (1 - t) * A[None] + t * B[None]
 
 
-def lj(x, hessian=False):
-    """12-6 LJ energy (hartree), gradient (N,3) and optionally Hessian (3N,3N)."""
+def lj(x, hessian=False, as_reference_calculator=False):
+    """12-6 LJ energy (hartree), gradient (N,3) and optionally Hessian (3N,3N).
+    as_reference_calculator=True reproduces what the reference's `-os lj` calculator hands out as its "exact" Hessian
+    (Calculator/lj_calculation_tools.py:112-118 takes phi'/r with the opposite sign); only the driver goldens (G8), which
+    were produced with that calculator, need it."""
     x = np.asarray(x, dtype=float).reshape(-1, 3)
     N = x.shape[0]
     d = x[:, None, :] - x[None, :, :]
@@ -63,7 +66,8 @@ def lj(x, hessian=False):
             if a == b:
                 continue
             dd = d[a, b]
-            blk = (h2[a, b] - f[a, b]) * np.outer(dd, dd) / r2[a, b] + f[a, b] * np.eye(3)
+            fr = -f[a, b] if as_reference_calculator else f[a, b]
+            blk = (h2[a, b] - fr) * np.outer(dd, dd) / r2[a, b] + fr * np.eye(3)
             H[3 * a:3 * a + 3, 3 * b:3 * b + 3] -= blk
             H[3 * a:3 * a + 3, 3 * a:3 * a + 3] += blk
     return E, G, H
@@ -101,3 +105,32 @@ def sy_pair(H, seed=1, kind="normal"):
     else:
         raise ValueError(kind)
     return s, y
+
+
+class LJCalculator:
+    """A Calculator plugin for argon clusters: the same interface and Hessian hand-over as the reference's
+    `-os lj` calculator (Calculator/lj_calculation_tools.py:209-264), fed by the analytic `lj` above.  Upstream of the
+    optimizer-step path; used by the driver tests only."""
+
+    def __init__(self, FC_COUNT=-1, project=None, as_reference_calculator=True):
+        self.as_reference_calculator = as_reference_calculator
+        self.FC_COUNT = FC_COUNT
+        self.hessian_flag = False
+        self.Model_hess = None
+        self.xtb_method = ""
+        self._project = project            # callable(H, x_bohr) -> TR/rot-projected Hessian (calc_exact_hess)
+
+    def calc_exact_hess(self, x_bohr):
+        H = lj(x_bohr, hessian=True, as_reference_calculator=self.as_reference_calculator)[2]
+        self.Model_hess = self._project(H, x_bohr)
+
+    def single_point(self, file_directory, element_list, iter, electric_charge_and_multiplicity, method="", geom_num_list=None):
+        x_ang = np.array(geom_num_list, dtype="float64").reshape(-1, 3)
+        x_bohr = x_ang / BOHR2ANG
+        e, g = lj(x_bohr)[:2]
+        if self.FC_COUNT == -1 or isinstance(iter, str):
+            if self.hessian_flag:
+                self.calc_exact_hess(x_bohr)
+        elif iter % self.FC_COUNT == 0 or self.hessian_flag:
+            self.calc_exact_hess(x_bohr)
+        return e, g, x_bohr, False

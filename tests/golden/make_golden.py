@@ -425,9 +425,127 @@ def g7_neb_step():
     print("G7 done")
 
 
+def g9_trust_radius():
+    """G9: TrustRadius.update_trust_radii sequences (trust_radius.py:120-206) on synthetic (E, g, s, H) histories."""
+    from multioptpy.Optimizer.trust_radius import TrustRadius
+    out = {}
+    for c, (n, seed, tmax, tmin) in enumerate([(21, 3, None, None), (21, 4, 0.3, 0.05), (39, 5, None, None), (9, 6, 0.1, None)]):
+        rng = np.random.default_rng(seed)
+        H = cases.spd_matrix(n, seed=seed)
+        TR = TrustRadius()
+        if tmax is not None:
+            TR.set_max_trust_radius(tmax)
+        if tmin is not None:
+            TR.set_min_trust_radius(tmin)
+        tr = 0.5 if tmax is None else tmax
+        x = np.zeros(n)
+        res = []
+        for k in range(14):
+            g = 0.02 * rng.normal(size=n)
+            mv = 0.05 * rng.normal(size=n)
+            if k % 4 == 1:
+                mv *= tr / np.linalg.norm(mv)              # a step that was limited by the trust radius
+            if k % 5 == 3:
+                mv *= 1e-5                                 # |Ce| below the precision threshold
+            pred = float(g @ mv + 0.5 * mv @ H @ mv)
+            e0 = float(rng.normal())
+            e1 = e0 - pred * (1.0 + (0.1, 0.6, 2.5, -0.5, 0.02)[k % 5] * rng.normal())
+            with quiet():
+                tr = float(TR.update_trust_radii(e1, e0, g.reshape(-1, 1), mv.reshape(-1, 1), H, x.reshape(-1, 1), tr))
+            out[f"c{c}_k{k}_g"] = g; out[f"c{c}_k{k}_mv"] = mv; out[f"c{c}_k{k}_e"] = np.array([e1, e0])
+            res.append(tr)
+        out[f"c{c}_H"] = H
+        out[f"c{c}_meta"] = np.array([n, 14, -1.0 if tmax is None else tmax, -1.0 if tmin is None else tmin])
+        out[f"c{c}_tr"] = np.array(res)
+    out["ncases"] = np.array(4)
+    np.savez_compressed(os.path.join(HERE, "g9_trust_radius.npz"), **out)
+    print("G9: 4 sequences")
+
+
+def _run_optmain(tag, N, argv, out, scale=0.92, jitter=0.3):
+    """Run the unmodified optmain driver (multioptpy/optimization.py) with the LJ calculator in a scratch directory and
+    record, per iteration, what goes into and comes out of CalculateMoveVector.calc_move_vector, the convergence test,
+    and the trust radius; plus the final geometry and the energy_profile.csv rows."""
+    import multioptpy.interface
+    import multioptpy.optimization
+    import multioptpy.optimizer
+    stub = types.ModuleType("multioptpy.Calculator.ase_calculation_tools")
+    stub.ASEEngine = stub.Calculation = type("ASEUnavailable", (), {})
+    sys.modules.setdefault(stub.__name__, stub)
+    x0 = cases.cluster(N, jitter=jitter) * scale * cases.BOHR2ANG          # angstrom, as the XYZ file holds it
+    cwd = os.getcwd()
+    rec = []
+    conv = []
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            with open("ar.xyz", "w") as f:
+                f.write(f"{N}\n0 1\n")
+                for r in x0:
+                    f.write(f"Ar {r[0]:.10f} {r[1]:.10f} {r[2]:.10f}\n")
+            parser = multioptpy.interface.init_parser()
+            args = multioptpy.interface.optimizeparser(parser, ["ar.xyz", "-os", "lj"] + argv)
+            CMV = multioptpy.optimizer.CalculateMoveVector
+            CC = multioptpy.optimization.ConvergenceChecker
+            orig, orig_cc = CMV.calc_move_vector, CC.check_convergence
+
+            def wrap(self, it, geom, B_g, pre_B_g, pre_geom, B_e, pre_B_e, pre_mv, init, g, pre_g, insts, pc=False, print_flag=True):
+                r = dict(geom=np.array(geom, dtype=float), B_g=np.array(B_g, dtype=float), B_e=float(B_e), pre_B_e=float(pre_B_e))
+                o = orig(self, it, geom, B_g, pre_B_g, pre_geom, B_e, pre_B_e, pre_mv, init, g, pre_g, insts, pc, print_flag)
+                r.update(tr=float(self.trust_radii), new=np.array(o[0], dtype=float), mv=np.array(o[1], dtype=float),
+                         H=np.array(insts[0].hessian, dtype=float), opt_tr=float(getattr(insts[0], "trust_radius", np.nan)))
+                rec.append(r)
+                return o
+
+            def wrap_cc(self, state, disp, insts):
+                o = orig_cc(self, state, disp, insts)
+                conv.append((bool(o[0]), float(o[1]), float(o[2]), np.array(disp, dtype=float)))
+                return o
+
+            CMV.calc_move_vector, CC.check_convergence = wrap, wrap_cc
+            try:
+                with quiet():
+                    bpa = multioptpy.optimization.Optimize(args)
+                    bpa.run()
+            finally:
+                CMV.calc_move_vector, CC.check_convergence = orig, orig_cc
+            import glob
+            prof = glob.glob(os.path.join(td, "*", "*", "energy_profile.csv"))
+            rows = [ln.strip().split(",") for ln in open(prof[0]).read().splitlines()[1:]] if prof else []
+            opt = glob.glob(os.path.join(td, "*", "*", "*_optimized.xyz"))
+            final = None
+            if opt:
+                lines = open(opt[0]).read().splitlines()[2:2 + N]
+                final = np.array([[float(v) for v in ln.split()[1:4]] for ln in lines])
+        finally:
+            os.chdir(cwd)
+    out[tag + "_x0_ang"] = x0
+    out[tag + "_argv"] = np.array(" ".join(argv))
+    out[tag + "_nit"] = np.array(len(rec))
+    for k, r in enumerate(rec):
+        for key in ("geom", "B_g", "new", "mv", "H"):
+            out[f"{tag}_i{k}_{key}"] = r[key]
+        out[f"{tag}_i{k}_sc"] = np.array([r["B_e"], r["pre_B_e"], r["tr"], r["opt_tr"]])
+        out[f"{tag}_i{k}_conv"] = np.array([float(conv[k][0]), conv[k][1], conv[k][2]])
+        out[f"{tag}_i{k}_disp"] = conv[k][3]
+    out[tag + "_profile"] = np.array([[float(v) for v in row] for row in rows]) if rows else np.zeros((0, 0))
+    if final is not None:
+        out[tag + "_final_ang"] = final
+    print("G8", tag, "iterations:", len(rec), "converged:", bool(conv and conv[-1][0]))
+
+
+def g8_optmain():
+    """G8: per-iteration trajectories of the reference's own optmain driver (Ar clusters, -os lj)."""
+    out = {}
+    _run_optmain("a", 7, ["-opt", "rsirfo_bfgs", "-ns", "8"], out)
+    _run_optmain("b", 13, ["-opt", "rsirfo_block_fsb", "-ns", "8", "-fc", "5"], out)
+    _run_optmain("c", 7, ["-opt", "rsprfo_bofill", "-order", "1", "-ns", "6", "-fc", "5"], out)
+    np.savez_compressed(os.path.join(HERE, "g8_optmain.npz"), **out)
+
+
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9"]
     if "g1" in which:
         g1_updates()
     if "g2" in which:
@@ -444,3 +562,7 @@ if __name__ == "__main__":
         g6b_neb_variants()
     if "g7" in which:
         g7_neb_step()
+    if "g8" in which:
+        g8_optmain()
+    if "g9" in which:
+        g9_trust_radius()

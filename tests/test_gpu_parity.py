@@ -420,3 +420,68 @@ sys.exit(1)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     print(r.stdout, r.stderr[-2000:])
     assert r.returncode == 0
+
+
+def test_kabsch_vs_reference(ops):
+    """a20: Kabsch on the device against the reference's output (G5), incl. the in-place centring of the drop-in class."""
+    from multioptpy_amd.Utils.calc_tools import Calculationtools
+    z = np.load(os.path.join(G, "g5_projections.npz"))
+    keys = [k for k in z.files if "kabsch" in k]
+    assert keys, z.files
+    P, Q = z["kabsch_P"].copy(), z["kabsch_Q"].copy()
+    Pa, Qc = ops.kabsch(P, Q)
+    assert np.abs(Pa - z["kabsch_Pout"]).max() < 1e-12 and np.abs(Qc - z["kabsch_Qout"]).max() < 1e-12
+    P2, Q2 = z["kabsch_P"].copy(), z["kabsch_Q"].copy()
+    Pr, Qr = Calculationtools().kabsch_algorithm(P2, Q2)
+    assert Qr is Q2 and np.abs(Q2 - z["kabsch_Qout"]).max() < 1e-12 and np.abs(P2.mean(axis=0)).max() < 1e-12
+    # planar and random cases against the oracle
+    from oracle import projection as pj
+    rng = np.random.default_rng(5)
+    for N, planar in ((3, True), (4, True), (7, False), (100, False)):
+        A = rng.normal(size=(N, 3))
+        if planar:
+            A[:, 2] = 0.0
+        th = 0.7
+        Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+        B = A @ Rz.T + 0.01 * rng.normal(size=(N, 3)) * (0 if planar else 1) + 0.3
+        ref, _ = pj.kabsch(A.copy(), B.copy())
+        got, _ = ops.kabsch(A, B)
+        assert np.abs(got - ref).max() < 1e-11, (N, planar)
+
+
+def test_outer_trust_radius_vs_reference():
+    """a15: TrustRadius.update_trust_radii sequences (G9), predicted energy change on the device."""
+    from multioptpy_amd.Optimizer.trust_radius import TrustRadius
+    z = np.load(os.path.join(G, "g9_trust_radius.npz"))
+    for c in range(int(z["ncases"])):
+        n, nk, tmax, tmin = z[f"c{c}_meta"]
+        TR = TrustRadius()
+        if tmax > 0:
+            TR.set_max_trust_radius(float(tmax))
+        if tmin > 0:
+            TR.set_min_trust_radius(float(tmin))
+        tr = 0.5 if tmax < 0 else float(tmax)
+        H = z[f"c{c}_H"]
+        for k in range(int(nk)):
+            e1, e0 = z[f"c{c}_k{k}_e"]
+            tr = float(TR.update_trust_radii(e1, e0, z[f"c{c}_k{k}_g"].reshape(-1, 1), z[f"c{c}_k{k}_mv"].reshape(-1, 1), H,
+                                             np.zeros((int(n), 1)), tr))
+            assert abs(tr - z[f"c{c}_tr"][k]) < 1e-12, (c, k)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_optmain_driver_vs_reference(tag):
+    """a15/a20/a23: the in-memory optmain iteration on the device path against the reference driver's own trajectory (G8):
+    geometry, move vector, new geometry, Hessian, outer trust radius, displacement and convergence thresholds per iteration."""
+    import cases
+    from oracle import projection as pj
+    from multioptpy_amd import drivers
+    from test_oracle_golden import _check_optmain
+    z = np.load(os.path.join(G, "g8_optmain.npz"))
+
+    def run(x0, elems, method, order, nstep, fc, rec):
+        calc = cases.LJCalculator(FC_COUNT=fc, project=pj.project_hessian_trrot)      # the Calculator is upstream of the path
+        drivers.optmain_steps(calc, x0, elems, method, order, nstep, fc, record=rec)
+
+    worst = _check_optmain(run, z, tag, 1e-8)
+    print("optmain", tag, "worst move-vector deviation from the reference", worst)

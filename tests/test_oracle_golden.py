@@ -222,3 +222,66 @@ def test_g3_rsprfo_traces():
             ts = int(z[f"{tag}_s{k}_tsidx"])
             if opt.saddle_order == 1:      # order 2: both shifted modes sit at -0.001, the tracked index is gauge dependent
                 assert (opt.ts_mode_idx is None and ts == -1) or int(opt.ts_mode_idx) == ts, (tag, k)
+
+
+def test_g9_outer_trust_radius():
+    """a15: TrustRadius.update_trust_radii sequences."""
+    from oracle.driver import TrustRadius
+    z = np.load(os.path.join(G, "g9_trust_radius.npz"))
+    for c in range(int(z["ncases"])):
+        n, nk, tmax, tmin = z[f"c{c}_meta"]
+        TR = TrustRadius()
+        if tmax > 0:
+            TR.set_max_trust_radius(float(tmax))
+        if tmin > 0:
+            TR.set_min_trust_radius(float(tmin))
+        tr = 0.5 if tmax < 0 else float(tmax)
+        H = z[f"c{c}_H"]
+        for k in range(int(nk)):
+            e1, e0 = z[f"c{c}_k{k}_e"]
+            tr = TR.update_trust_radii(e1, e0, z[f"c{c}_k{k}_g"], z[f"c{c}_k{k}_mv"], H, np.zeros(int(n)), tr)
+            assert abs(tr - z[f"c{c}_tr"][k]) < 1e-14, (c, k)
+
+
+def _check_optmain(run, z, tag, tol):
+    import cases
+    argv = str(z[tag + "_argv"]).split()
+    method = argv[argv.index("-opt") + 1]
+    order = int(argv[argv.index("-order") + 1]) if "-order" in argv else 0
+    fc = int(argv[argv.index("-fc") + 1]) if "-fc" in argv else -1
+    nstep = int(argv[argv.index("-ns") + 1])
+    x0 = z[tag + "_x0_ang"]
+    # the start file holds 10 decimals
+    x0 = np.array([[float(f"{v:.10f}") for v in r] for r in x0])
+    rec = []
+    run(x0, ["Ar"] * len(x0), method, order, nstep, fc, rec)
+    assert len(rec) == int(z[tag + "_nit"])
+    worst = 0.0
+    for k, r in enumerate(rec):
+        sc = z[f"{tag}_i{k}_sc"]
+        assert np.abs(r["geom"] - z[f"{tag}_i{k}_geom"]).max() < tol, (tag, k, "geom")
+        assert abs(r["B_e"] - sc[0]) < 1e-12 and abs(r["tr"] - sc[2]) < 1e-12, (tag, k, "scalars")
+        d = np.abs(r["mv"] - z[f"{tag}_i{k}_mv"]).max()
+        worst = max(worst, d)
+        assert d < tol, (tag, k, "move_vector", d)
+        assert np.abs(r["new"] - z[f"{tag}_i{k}_new"]).max() < tol, (tag, k, "new_geometry")
+        assert np.abs(r["H"] - z[f"{tag}_i{k}_H"]).max() < 1e-8, (tag, k, "hessian")
+        cv = z[f"{tag}_i{k}_conv"]
+        assert bool(cv[0]) == r["conv"][0] and abs(cv[1] - r["conv"][1]) < 1e-12 and abs(cv[2] - r["conv"][2]) < 1e-12
+        assert np.abs(r["disp"] - z[f"{tag}_i{k}_disp"]).max() < tol, (tag, k, "displacement")
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g8_optmain_driver(tag):
+    """a15/a20/a23: the oracle's in-memory optmain iteration against the reference driver's own trajectory."""
+    import cases
+    from oracle import driver, projection as pj
+    z = np.load(os.path.join(G, "g8_optmain.npz"))
+
+    def run(x0, elems, method, order, nstep, fc, rec):
+        calc = cases.LJCalculator(FC_COUNT=fc, project=pj.project_hessian_trrot)
+        driver.run_optmain(calc, x0, elems, method, order, nstep, fc, record=rec)
+
+    worst = _check_optmain(run, z, tag, 1e-9)
+    print("optmain", tag, "worst move-vector deviation", worst)
