@@ -26,9 +26,19 @@ class RFOOptimizer:
         self.device = device
         self.band = None
         self.optimizer_instance_list = []     # kept for API compatibility (state lives on the device)
+        self._pending_hessians = None         # in-memory counterpart of the tmp_hessian_i.npy side channel
 
     def set_apply_ts_opt(self, apply_ts_opt):
         self.apply_ts_opt = apply_ts_opt
+
+    def set_image_hessians(self, hessians):
+        """Hand over one Hessian per image (or None to keep an image's current one) for the next `optimize` call: what the
+        calculators do in the reference by writing tmp_hessian_{i}.npy (e.g. lj_calculation_tools.py:350-353)."""
+        self._pending_hessians = list(hessians)
+
+    def get_image_hessian(self, i):
+        """The Hessian of image i as the reference would find it in tmp_hessian_{i}.npy after the step."""
+        return self.band.get_hessian(i)
 
     def _file(self, i):
         return os.path.join(self.folder, f"tmp_hessian_{i}.npy")
@@ -52,6 +62,11 @@ class RFOOptimizer:
             for i in range(I):
                 f = self._file(i)
                 self.band.set_hessian(i, np.load(f) if os.path.exists(f) else None)
+        if self._pending_hessians is not None:
+            for i, h in enumerate(self._pending_hessians):
+                if h is not None:
+                    self.band.set_hessian(i, np.asarray(h, dtype=np.float64))
+            self._pending_hessians = None
         self.band.upload(X, E, G)
         self.band.step(optimize_num)
         newX, F = self.band.download(want_force=True)

@@ -129,3 +129,76 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
         pre_move_vector = move_vector
         geometry = new_geometry / BOHR2ANGSTROMS
     return dict(converged=converged, iterations=it + 1, geometry_bohr=geometry, energy=energy)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# nebmain (multioptpy/neb.py:489-601), RFO branch
+# ---------------------------------------------------------------------------------------------------------------------
+def make_band(frames_ang, partition):
+    """NEB.make_geometry_list (neb.py:1013-1096) for plain linear interpolation: `partition` extra nodes per segment; the
+    first frame appears twice, as in the reference (images = 1 + (partition + 1)(frames - 1) + 1)."""
+    frames = [np.array(f, dtype="float64") for f in frames_ang]
+    nodes = []
+    for k in range(len(frames) - 1):
+        delta = (frames[k + 1] - frames[k]) / (partition + 1)
+        for i in range(partition + 1):
+            nodes.append(frames[k] + delta * i)
+    nodes.append(frames[-1])
+    return np.array([frames[0]] + nodes, dtype="float64")
+
+
+def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
+                  ratio_of_rfo_step=0.5, quantise=True, record=None, device=None):
+    """Band relaxation with the Hessian-based branch of nebmain (`-fc`/`-modelhess`: RFOOptimizer on a BNEB force).
+    `engine.calculate(X_ang (I,N,3), optimize_num)` -> (E (I,), G (I,N,3), X_bohr (I,N,3), hessians | None) is the in-memory
+    form of the reference's Engine.calculate and its tmp_hessian_i.npy side channel.  Per iteration, in the reference's order
+    (neb.py:497-597): energies/gradients -> BNEB force -> RFOOptimizer.optimize (which recomputes the force, rfo_neb.py:131)
+    -> edge fixing -> sequential Kabsch k -> k+1 (centres image k+1 in place) -> `%17.12f` quantisation."""
+    from .MEP.pathopt_bneb_force import CaluculationBNEB
+    from .Optimizer.rfo_neb import RFOOptimizer
+
+    class _Config:
+        pass
+
+    config = _Config()
+    config.NEB_FOLDER_DIRECTORY = None
+    config.fix_init_edge = fixedges in (1,) or fixedges >= 3
+    config.fix_end_edge = fixedges in (2,) or fixedges >= 3
+    config.ratio_of_rfo_step = ratio_of_rfo_step
+    geometry_ang = make_band(frames_ang, partition)
+    if quantise:
+        geometry_ang = np.array([quantise_xyz(x) for x in geometry_ang])
+    STRING_FORCE_CALC = CaluculationBNEB(APPLY_CI_NEB)
+    optimizer = RFOOptimizer(config, persist_hessians=False, device=device)
+    tools = Calculationtools()
+    pre_geom = pre_gradients = None
+    pre_total_velocity = []
+    init_geometry = None
+    for optimize_num in range(NSTEP):
+        E, G, X, hessians = engine.calculate(geometry_ang, optimize_num)
+        E = np.asarray(E, dtype="float64")
+        G = np.asarray(G, dtype="float64")
+        X = np.asarray(X, dtype="float64")
+        if hessians is not None:
+            optimizer.set_image_hessians(hessians)
+        if optimize_num == 0:
+            init_geometry = X
+        total_force = STRING_FORCE_CALC.calc_force(X, E, G, optimize_num, element_list)
+        total_velocity = np.array(total_force, dtype="float64")            # NEB.force2velocity (neb.py:1159-1162)
+        new_geometry = np.array(optimizer.optimize(X, G, pre_geom, pre_gradients, optimize_num, E, E, pre_total_velocity,
+                                                   total_velocity, None, pre_geom, STRING_FORCE_CALC), dtype="float64")
+        opt_out = new_geometry.copy() if record is not None else None
+        # NEB._apply_constraints (neb.py:966-998), no fixed atoms
+        if config.fix_init_edge:
+            new_geometry[0] = init_geometry[0] * BOHR2ANGSTROMS
+        if config.fix_end_edge:
+            new_geometry[-1] = init_geometry[-1] * BOHR2ANGSTROMS
+        for k in range(len(new_geometry) - 1):
+            aligned, _ = tools.kabsch_algorithm(new_geometry[k], new_geometry[k + 1])
+            new_geometry[k] = copy.copy(aligned)
+        if record is not None:
+            record.append(dict(E=E.copy(), G=G.copy(), X=X.copy(), opt=opt_out, post=new_geometry.copy(),
+                               hess=[optimizer.get_image_hessian(i) for i in range(len(X))]))
+        pre_geom, pre_gradients, pre_total_velocity = copy.copy(X), copy.copy(G), copy.copy(total_velocity)
+        geometry_ang = np.array([quantise_xyz(x) for x in new_geometry]) if quantise else new_geometry
+    return geometry_ang

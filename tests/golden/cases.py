@@ -134,3 +134,30 @@ class LJCalculator:
         elif iter % self.FC_COUNT == 0 or self.hessian_flag:
             self.calc_exact_hess(x_bohr)
         return e, g, x_bohr, False
+
+
+class LJEngine:
+    """In-memory NEB engine for argon bands: energies/gradients of every image and, every FC_COUNT iterations, the
+    TR/rot-projected Hessians the reference's LJEngine writes to tmp_hessian_i.npy (lj_calculation_tools.py:290-366)."""
+
+    def __init__(self, FC_COUNT=-1, project=None, as_reference_calculator=True, MFC_COUNT=50):
+        self.FC_COUNT = FC_COUNT
+        self.MFC_COUNT = MFC_COUNT
+        self._project = project
+        self.as_reference_calculator = as_reference_calculator
+
+    def calculate(self, X_ang, optimize_num):
+        X = np.asarray(X_ang, dtype="float64") / BOHR2ANG
+        I = X.shape[0]
+        E = np.zeros(I)
+        G = np.zeros_like(X)
+        for i in range(I):
+            E[i], G[i] = lj(X[i])[:2]
+        hess = None
+        # With its default -mfc 50 and no model Hessian the reference's engine raises (and swallows) an AttributeError on
+        # iterations that are multiples of 50, iteration 0 included, before it reaches the exact-Hessian branch
+        # (lj_calculation_tools.py:336-353): no Hessians are delivered there.
+        skipped = self.as_reference_calculator and self.MFC_COUNT != -1 and optimize_num % self.MFC_COUNT == 0
+        if self.FC_COUNT != -1 and optimize_num % self.FC_COUNT == 0 and not skipped:
+            hess = [self._project(lj(X[i], hessian=True, as_reference_calculator=self.as_reference_calculator)[2], X[i]) for i in range(I)]
+        return E, G, X, hess

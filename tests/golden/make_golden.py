@@ -543,9 +543,90 @@ def g8_optmain():
     np.savez_compressed(os.path.join(HERE, "g8_optmain.npz"), **out)
 
 
+def _run_nebmain(tag, N, argv, out):
+    """Run the unmodified nebmain driver (multioptpy/neb.py) with the LJ engine in a scratch directory.  Per iteration:
+    what the engine returned (E, G, X read back from the XYZ files), the tmp_hessian_i.npy files the optimizer saw, what
+    RFOOptimizer.optimize returned, and the geometry after constraints/Kabsch chain that goes to the next input files."""
+    stub = types.ModuleType("multioptpy.Calculator.ase_calculation_tools")      # the one unguarded ASE import (SURVEY 8(c))
+    stub.ASEEngine = stub.Calculation = type("ASEUnavailable", (), {})
+    sys.modules.setdefault(stub.__name__, stub)
+    import multioptpy.interface
+    import multioptpy.neb
+    from multioptpy.Optimizer import rfo_neb
+    from multioptpy.Calculator import lj_calculation_tools as ljt
+    X = cases.band(8, N)
+    cwd = os.getcwd()
+    calc_rec, opt_rec, post_rec = [], [], []
+    with tempfile.TemporaryDirectory() as td:
+        os.chdir(td)
+        try:
+            os.makedirs("ends")
+            for k, x in enumerate((X[0], X[-1])):
+                with open(f"ends/ar_{k}.xyz", "w") as f:
+                    f.write(f"{N}\n0 1\n")
+                    for r in x * cases.BOHR2ANG:
+                        f.write(f"Ar {r[0]:.10f} {r[1]:.10f} {r[2]:.10f}\n")
+            parser = multioptpy.interface.init_parser()
+            args = multioptpy.interface.nebparser(parser, ["ends", "-os", "lj"] + argv)
+            o_calc, o_opt, o_print = ljt.LJEngine.calculate, rfo_neb.RFOOptimizer.optimize, multioptpy.neb.NEB.print_geometry_list
+
+            def w_calc(self, file_directory, optimize_num, pre_total_velocity, config):
+                r = o_calc(self, file_directory, optimize_num, pre_total_velocity, config)
+                calc_rec.append((np.array(r[0]), np.array(r[1]), np.array(r[2])))
+                return r
+
+            def w_opt(self, geom, grads, pre_geom, pre_grads, optimize_num, E, *rest):
+                import glob
+                hs = {}
+                for f in glob.glob(os.path.join(self.config.NEB_FOLDER_DIRECTORY, "tmp_hessian_*.npy")):
+                    hs[int(os.path.basename(f)[len("tmp_hessian_"):-4])] = np.load(f)
+                o = o_opt(self, geom, grads, pre_geom, pre_grads, optimize_num, E, *rest)
+                hs_after = {}
+                for f in glob.glob(os.path.join(self.config.NEB_FOLDER_DIRECTORY, "tmp_hessian_*.npy")):
+                    hs_after[int(os.path.basename(f)[len("tmp_hessian_"):-4])] = np.load(f)
+                opt_rec.append((np.array(o, dtype=float), hs, hs_after))
+                return o
+
+            def w_print(self, new_geometry, element_list, cm):
+                post_rec.append(np.array(new_geometry, dtype=float))
+                return o_print(self, new_geometry, element_list, cm)
+
+            ljt.LJEngine.calculate, rfo_neb.RFOOptimizer.optimize, multioptpy.neb.NEB.print_geometry_list = w_calc, w_opt, w_print
+            try:
+                with quiet():
+                    neb = multioptpy.neb.NEB(args)
+                    neb.run()
+            finally:
+                ljt.LJEngine.calculate, rfo_neb.RFOOptimizer.optimize, multioptpy.neb.NEB.print_geometry_list = o_calc, o_opt, o_print
+        finally:
+            os.chdir(cwd)
+    nit = len(opt_rec)
+    post = post_rec[-nit:]                    # (print_geometry_list is also called once while the input band is set up)
+    out[tag + "_argv"] = np.array(" ".join(argv))
+    out[tag + "_ends_bohr"] = np.array([X[0], X[-1]])
+    out[tag + "_nit"] = np.array(nit)
+    for k in range(nit):
+        out[f"{tag}_i{k}_E"], out[f"{tag}_i{k}_G"], out[f"{tag}_i{k}_X"] = calc_rec[k]
+        out[f"{tag}_i{k}_opt"] = opt_rec[k][0]
+        out[f"{tag}_i{k}_post"] = post[k]
+        for i, h in opt_rec[k][1].items():
+            out[f"{tag}_i{k}_hin{i}"] = h
+        for i, h in opt_rec[k][2].items():
+            out[f"{tag}_i{k}_hout{i}"] = h
+    print("G8 neb", tag, "iterations:", nit, "images:", calc_rec[0][0].shape[0])
+
+
+def g8_nebmain():
+    """G8 (NEB half): the reference's nebmain loop on an Ar7 band, RFO branch, exact Hessians every 3 iterations."""
+    out = {}
+    _run_nebmain("n", 7, ["-fc", "3", "-ns", "5", "-p", "5"], out)
+    _run_nebmain("e", 7, ["-fc", "2", "-ns", "4", "-p", "5", "-fe", "3"], out)
+    np.savez_compressed(os.path.join(HERE, "g8_nebmain.npz"), **out)
+
+
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9"]
     if "g1" in which:
         g1_updates()
     if "g2" in which:
@@ -564,5 +645,7 @@ if __name__ == "__main__":
         g7_neb_step()
     if "g8" in which:
         g8_optmain()
+    if "g8n" in which:
+        g8_nebmain()
     if "g9" in which:
         g9_trust_radius()

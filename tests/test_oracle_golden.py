@@ -285,3 +285,42 @@ def test_g8_optmain_driver(tag):
 
     worst = _check_optmain(run, z, tag, 1e-9)
     print("optmain", tag, "worst move-vector deviation", worst)
+
+
+def _check_nebmain(run, z, tag, tol):
+    argv = str(z[tag + "_argv"]).split()
+    fc = int(argv[argv.index("-fc") + 1])
+    nstep = int(argv[argv.index("-ns") + 1])
+    p = int(argv[argv.index("-p") + 1])
+    fe = int(argv[argv.index("-fe") + 1]) if "-fe" in argv else 0
+    ends = z[tag + "_ends_bohr"] * cases.BOHR2ANG
+    ends = np.array([[[float(f"{v:.10f}") for v in r] for r in x] for x in ends])       # the start files hold 10 decimals
+    rec = []
+    run(ends, fc, nstep, p, fe, rec)
+    assert len(rec) == int(z[tag + "_nit"])
+    worst = 0.0
+    for k, r in enumerate(rec):
+        assert np.abs(r["X"] - z[f"{tag}_i{k}_X"]).max() < tol, (tag, k, "geometry read by the engine")
+        assert np.abs(r["E"] - z[f"{tag}_i{k}_E"]).max() < 1e-10, (tag, k, "energies")
+        d = np.abs(r["opt"] - z[f"{tag}_i{k}_opt"]).max()
+        worst = max(worst, d)
+        assert d < tol, (tag, k, "optimizer output", d)
+        assert np.abs(r["post"] - z[f"{tag}_i{k}_post"]).max() < tol, (tag, k, "after constraints + Kabsch chain")
+        for i in range(len(r["hess"])):
+            key = f"{tag}_i{k}_hout{i}"
+            if key in z.files:
+                assert np.abs(r["hess"][i] - z[key]).max() < 1e-8, (tag, k, i, "Hessian after the step")
+    return worst
+
+
+@pytest.mark.parametrize("tag", ["n", "e"])
+def test_g8_nebmain_driver(tag):
+    """a23: the oracle's in-memory nebmain iteration (RFO branch) against the reference driver's own band trajectory."""
+    from oracle import driver
+
+    def run(ends, fc, nstep, p, fe, rec):
+        eng = cases.LJEngine(FC_COUNT=fc, project=pj.project_hessian_trrot)
+        driver.run_nebmain(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, literal=True)
+
+    worst = _check_nebmain(run, np.load(os.path.join(G, "g8_nebmain.npz")), tag, 1e-9)
+    print("nebmain", tag, "worst optimizer-output deviation", worst)
