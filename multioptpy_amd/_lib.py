@@ -9,7 +9,7 @@ import numpy as np
 from . import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmopt_hip.so")
+LIB_PATH = os.environ.get("MOPT_HIP_LIB") or os.path.join(_HERE, "libmopt_hip.so")      # override: A/B builds of the same ABI
 
 DP = C.POINTER(C.c_double)
 IP = C.POINTER(C.c_int)

@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[64];
     __shared__ int s_fail;
-    long long t_poll = 0, t_pro = 0, t_main = 0, t_loop = 0, t_bar = 0, t0 = 0, t1 = 0;
+    long long t_poll = 0, t_pro = 0, t_main = 0, t_loop = 0, t_bar = 0, t_p1 = 0, t_p2 = 0, t0 = 0, t1 = 0, t2 = 0;
     double *sva = sm, *sw = sm + n, *svb = sm + 2 * n;      // reflector ping-pong (sva/svb), w
     double *accp = sm + 3 * n;                              // [RG][n] partial SYMV per row group
     double *Aloc = sm + (size_t)(3 + RG) * n;               // [rows_cap][n] rows owned by this workgroup
@@ -362,6 +362,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
             if (rg == 0 && lane == 0) red[wid] = pvw;
             if (mine && j == lo) red[16] = pj;
             lds_barrier();
+            if (prof) { t2 = wall_clock64(); t_p1 += t2 - t0; }
             double pv = 0.0;
             for (int w = 0; w < nw0; ++w) pv += red[w];
             const double c = -0.5 * tau * pv;
@@ -381,6 +382,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
             if (mine && j == lo + 1) red2[16] = r;
             if (mine && j == lo) red2[17] = r;
             lds_barrier();
+            if (prof) { t2 = wall_clock64(); t_p2 += t2 - t0; }
             double xn2 = 0.0;
             for (int w = 0; w < nw0; ++w) xn2 += red2[w];
             const double alpha = (lo + 1 < n) ? red2[16] : 0.0;
@@ -469,7 +471,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         if (RG == 1) lds_barrier();                         // (with RG > 1 the accp barrier already separates the steps)
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
     }
-    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; }
+    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; q[5] = t_p1; q[6] = t_p2; }
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
     // D[n-1]: owner of the last row
     {
@@ -478,6 +480,239 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         if (c % G == g && tid == 0 && !s_fail) {
             const int r = (c / G) * TRI_RC + (gi_last % TRI_RC);
             D[n - 1] = Aloc[(size_t)r * n + (n - 1)];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// k_tri_persist2: the same algorithm and hand-off as k_tri_persist with a different thread mapping of the LDS main pass.
+// 16 waves; wave w owns the live local rows r_first + w, + 16, ... and sweeps each row in CH = ceil(n / 64) column chunks
+// (lane <-> column lane + 64 q), so the three per-row scalars v_i, w_i, v'_i are fetched once per row and wave (LDS
+// broadcast) instead of once per row and column wave, and the per-column operands w_j, v_j and the SYMV partials stay in
+// registers.  The 16 per-wave partial vectors meet in LDS (accp[16][n]); thread j < n adds them in wave order.
+// The prologue (poll, w_k, reflector k+1) runs on the threads tid = column j < n exactly as in k_tri_persist.
+template <int CH>
+__global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_cap, double *__restrict__ A_, double *__restrict__ D_,
+                                                       double *__restrict__ E_, double *__restrict__ TAU_, u64 *__restrict__ XCH_,
+                                                       size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof) {
+    constexpr int NW = 16;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[64];
+    __shared__ int s_fail;
+    long long t_poll = 0, t_pro = 0, t_main = 0, t_loop = 0, t_bar = 0, t0 = 0, t1 = 0;
+    const long long c_start = prof ? clock64() : 0, w_start = prof ? wall_clock64() : 0;
+    double *sva = sm, *sw = sm + n, *svb = sm + 2 * n;      // reflector ping-pong (sva/svb), w
+    double *accp = sm + 3 * n;                              // [NW][n] partial SYMV per wave
+    double *Aloc = sm + (size_t)(3 + NW) * n;               // [rows_cap][n] rows owned by this workgroup
+    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int j = tid, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw0 = (n + 63) >> 6;                           // waves that carry columns in the prologue
+    const int chn = nw0, ns = 64 * chn;                      // column chunks in use, padded row stride of Aloc
+    double *A = A_ + (size_t)b * n * n;
+    double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
+    u64 *PARTX = XCH_ + (size_t)b * xch_stride;             // [2][G][n][2]
+    u64 *ROWX = PARTX + (size_t)4 * G * n;                  // [2][n][2]
+    if (tid == 0) s_fail = 0;
+    for (int i = tid; i < 3 * n; i += blockDim.x) sm[i] = 0.0;   // v, w, v': the branch-free main pass multiplies them by zero at k = -1
+    int r_end = 0;                                           // local rows that exist (global index < n)
+    for (int r = 0; r < rows_cap; ++r) r_end += ((g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC) < n) ? 1 : 0;
+    for (int r = wid; r < r_end; r += NW) {
+        const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+#pragma unroll
+        for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) Aloc[r * ns + jj] = (jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
+    }
+    __syncthreads();
+    if (g == 0 && j < n) ll_put(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u);     // row 0: tag 1 in buffer 1 (step k = -1)
+    double tau = 0.0, taun = 0.0;
+    double *sv = sva, *svn = svb;
+    for (int k = -1; k <= n - 3; ++k) {
+        const int lo = k + 1, cur = k & 1, nxt = cur ^ 1;
+        const int nk = k + 1;
+        const unsigned tag = (unsigned)(k + 2);
+        const u64 *PARTc = PARTX + (size_t)cur * G * n * 2;
+        u64 *PARTn = PARTX + (size_t)nxt * G * n * 2;
+        const u64 *ROWc = ROWX + (size_t)cur * n * 2;
+        u64 *ROWn = ROWX + (size_t)nxt * n * 2;
+        const bool mine = (j >= lo && j < n);
+        // ---- collect: the G partial SYMV vectors of step k and row lo, column j
+        double psum = 0.0, rowj = 0.0;
+        if (prof) t0 = wall_clock64();
+        if (mine) {
+            if (k >= 0) {
+                for (int u0 = 0; u0 < G; u0 += 8) {              // G is a multiple of 8: sixteen loads in flight
+                    u64 a[8], c[8];
+                    unsigned spins = 0;
+                    for (;;) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const u64 *q = &PARTc[((size_t)(u0 + u) * n + j) * 2];
+                            a[u] = ll_ld(q); c[u] = ll_ld(q + 1);
+                        }
+                        bool ok = true;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) ok = ok && ((unsigned)(a[u] >> 32) == tag) && ((unsigned)(c[u] >> 32) == tag);
+                        if (ok) break;
+                        if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) psum += ll_val(a[u], c[u]);
+                }
+            }
+            u64 a, c;
+            unsigned spins = 0;
+            for (;;) {
+                const u64 *q = &ROWc[(size_t)j * 2];
+                a = ll_ld(q); c = ll_ld(q + 1);
+                if ((unsigned)(a >> 32) == tag && (unsigned)(c >> 32) == tag) break;
+                if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            rowj = ll_val(a, c);
+        }
+        if (prof) { lds_barrier(); t1 = wall_clock64(); t_poll += t1 - t0; t0 = t1; }
+        // ---- w_k = p + c v  (p = tau A v, c = -tau/2 p.v); the failure flag of the polls is read behind the same barrier.
+        // Only the nw0 column waves do the arithmetic; the other waves just meet them at the barriers (they would otherwise
+        // share the SIMDs' issue slots with the critical path).
+// Two variants measured on one box (tools/build_variant.sh, n = 300, 32 matrices; ms per launch): all 16 waves run the
+// prologue redundantly / only the column waves do (MOPT_P2_CW): 1.862 / 1.889; idle waves and dead chunks also write accp /
+// are skipped (MOPT_P2_GUARD): 1.862 / 1.878; both: 1.948.  The simple forms stay the default.
+#ifndef MOPT_P2_CW
+#define MOPT_P2_CW 0
+#endif
+#ifndef MOPT_P2_GUARD
+#define MOPT_P2_GUARD 0
+#endif
+        const bool cw = MOPT_P2_CW ? (wid < nw0) : true;
+        double wj_own = 0.0, w_lo = 0.0, v_own = 0.0, v_lo = 0.0;
+        if (cw) { v_own = mine ? sv[j] : 0.0; v_lo = sv[lo]; }
+        if (k >= 0) {
+            double pj = 0.0;
+            if (cw) {
+                pj = tau * psum;
+                const double pvw = wave_sum(mine ? pj * v_own : 0.0);
+                if (lane == 0) red[wid] = pvw;
+                if (mine && j == lo) red[16] = pj;
+            }
+            lds_barrier();
+            if (s_fail) break;
+            if (cw) {
+                double pv = 0.0;
+                for (int w = 0; w < nw0; ++w) pv += red[w];
+                const double c = -0.5 * tau * pv;
+                wj_own = pj + c * v_own;
+                w_lo = red[16] + c * v_lo;
+                if (mine) sw[j] = wj_own;
+            }
+        }
+        // ---- reflector of step k+1 from the updated row lo
+        double *red2 = red + 32;
+        double r = rowj;
+        if (cw) {
+            if (mine && k >= 0 && tau != 0.0) r -= v_lo * wj_own + w_lo * v_own;
+            const double xw = wave_sum((mine && j >= lo + 2) ? r * r : 0.0);
+            if (lane == 0) red2[wid] = xw;
+            if (mine && j == lo + 1) red2[16] = r;
+            if (mine && j == lo) red2[17] = r;
+        }
+        lds_barrier();
+        if (s_fail) break;
+        if (cw) {
+            double xn2 = 0.0;
+            for (int w = 0; w < nw0; ++w) xn2 += red2[w];
+            const double alpha = (lo + 1 < n) ? red2[16] : 0.0;
+            const double diag = red2[17];
+            double scal = 0.0, betan = alpha;
+            taun = 0.0;
+            if (nk <= n - 3 && xn2 != 0.0) {
+                betan = -copysign(sqrt(alpha * alpha + xn2), alpha);
+                taun = (betan - alpha) / betan;
+                scal = 1.0 / (alpha - betan);
+            }
+            if (mine) svn[j] = (j == lo) ? 0.0 : (j == lo + 1) ? 1.0 : r * scal;
+            if (tid == 0) {
+                red2[20] = taun;
+                if (g == 0) { D[nk] = diag; E[nk] = betan; TAU[nk] = taun; if (nk == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; } }
+            }
+        }
+        lds_barrier();                                      // sw, svn, tau' complete
+        if (!cw) taun = red2[20];
+        if (k >= 0 && g == 0 && j >= k + 2 && j < n) A[(size_t)k * n + j] = sv[j];   // reflector k, dsytrd layout
+        if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
+        // ---- main pass: rank-2 update of the live rows with (v, w), partial SYMV with v'
+        const bool do_upd = (k >= 0 && tau != 0.0);
+        const bool do_mv = (taun != 0.0);
+        int nact = 0;
+        {
+            const int m = (lo + 1) / TRI_RC, sft = (lo + 1) % TRI_RC;
+            const bool own_next = (m >= g && (m - g) % G == 0);            // this workgroup holds global row lo + 1
+            int r_first;
+            if (own_next) r_first = ((m - g) / G) * TRI_RC + sft;
+            else r_first = (m < g) ? 0 : ((m - g + G - 1) / G) * TRI_RC;
+            const int q0 = (lo + 1) >> 6;                                   // first column chunk with a live column (j > lo)
+            // Branch-free inner loop: rows are padded to ns = 64 * ceil(n / 64) columns (pad stays zero), dead columns
+            // (j <= lo) get w_j = v_j = 0 so their entries are rewritten unchanged, a skipped update or SYMV is a zero
+            // scalar.  Only whole dead chunks are skipped (wave-uniform).
+            // Waves without a live row (late steps) and dead chunks touch neither their operands nor accp.
+            nact = r_end - r_first;
+            nact = nact < 0 ? 0 : (nact > NW ? NW : nact);
+            if (!MOPT_P2_GUARD) nact = NW;
+            const int q0g = MOPT_P2_GUARD ? q0 : 0;
+            double acc[CH], wj[CH], vj[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                const bool cl = (jj > lo && jj < n);
+                acc[q] = 0.0; wj[q] = 0.0; vj[q] = 0.0;
+                if (wid < nact && q >= q0g && q < chn && do_upd) { wj[q] = cl ? sw[jj] : 0.0; vj[q] = cl ? sv[jj] : 0.0; }
+            }
+            for (int rr = r_first + wid; rr < r_end; rr += NW) {
+                const int gi = (g + (rr / TRI_RC) * G) * TRI_RC + (rr % TRI_RC);
+                const double vi = -sv[gi], wi = -sw[gi], zi = do_mv ? svn[gi] : 0.0;          // LDS broadcasts
+                double *Ar = Aloc + rr * ns + lane;
+                double a[CH];
+#pragma unroll
+                for (int q = 0; q < CH; ++q) if (q >= q0 && q < chn) a[q] = Ar[64 * q];
+#pragma unroll
+                for (int q = 0; q < CH; ++q)
+                    if (q >= q0 && q < chn) {
+                        a[q] = fma(vi, wj[q], a[q]);
+                        a[q] = fma(wi, vj[q], a[q]);
+                        acc[q] = fma(a[q], zi, acc[q]);
+                    }
+#pragma unroll
+                for (int q = 0; q < CH; ++q) if (q >= q0 && q < chn) Ar[64 * q] = a[q];
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (wid < nact && q >= q0g && jj < n) accp[wid * n + jj] = acc[q]; }
+            // the wave that swept global row lo + 1 publishes it (same wave, program order: no barrier needed)
+            if (own_next && r_first < r_end && wid == 0) {
+                const double *Ar = Aloc + r_first * ns;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put(&ROWn[(size_t)jj * 2], Ar[jj], tag + 1u); }
+            }
+        }
+        if (prof) { t1 = wall_clock64(); t_loop += t1 - t0; t0 = t1; }
+        lds_barrier();
+        if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
+        if (j > lo && j < n) {
+            double a = 0.0;
+            for (int w = 0; w < nact; ++w) a += accp[w * n + j];
+            ll_put(&PARTn[((size_t)g * n + j) * 2], a, tag + 1u);
+        }
+        tau = taun;
+        { double *t = sv; sv = svn; svn = t; }
+        if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
+    }
+    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
+    __syncthreads();
+    if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
+    {
+        const int gi_last = n - 1;
+        const int c = gi_last / TRI_RC;
+        if (c % G == g && tid == 0 && !s_fail) {
+            const int r = (c / G) * TRI_RC + (gi_last % TRI_RC);
+            D[n - 1] = Aloc[r * ns + (n - 1)];
         }
     }
 }
@@ -827,7 +1062,51 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     while (G < 256 && lds_for(G) > (size_t)ctx->lds_limit - 4096) G *= 2;
     const bool persist = multi && !getenv("MOPT_TRI_NOPERSIST") && lds_for(G) <= (size_t)ctx->lds_limit - 4096 && G <= ctx->num_cu &&
                          n <= 1024 && 4 * G + 4 <= n;
-    if (persist) {
+    // row-per-wave variant (k_tri_persist2): 16 waves, accp[16][n]
+    int G2 = 8;
+    auto lds2_for = [&](int G_) { return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(3 + 16) * n) * 8; };
+    while (G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
+    const bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && lds2_for(G2) <= (size_t)ctx->lds_limit - 4096 &&
+                          G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 4 <= n;
+    if (persist2) {
+        mopt_scope sc(ctx, "eigh_tridiag", 1);
+        const int ch = (n + 63) / 64;
+        const void *fn = nullptr;
+#define P2(C) ((const void *)k_tri_persist2<C>)
+        fn = ch <= 1 ? P2(1) : ch <= 2 ? P2(2) : ch <= 3 ? P2(3) : ch <= 4 ? P2(4) : ch <= 5 ? P2(5) : ch <= 6 ? P2(6) : ch <= 8 ? P2(8)
+           : ch <= 10 ? P2(10) : ch <= 12 ? P2(12) : P2(16);
+#undef P2
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+        const int G = G2;
+        int rows = rows_for(G);
+        long long *d_prof = nullptr;
+        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
+        const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
+        const size_t xwords = ((size_t)4 * G + 4) * n;
+        MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
+        for (int b0 = 0; b0 < batch; b0 += per) {
+            const int nb_ = (batch - b0 < per) ? batch - b0 : per;
+            int n_ = n, G_ = G;
+            double *pA = d_A + (size_t)b0 * n * n, *pD = d_D + (size_t)b0 * n, *pE = d_E + (size_t)b0 * n, *pT = d_TAU + (size_t)b0 * n;
+            u64 *pX = (u64 *)(d_Vt + (size_t)b0 * n * n);
+            size_t stride = (size_t)n * n;
+            int *pF = d_fail + b0;
+            long long *pP = d_prof ? d_prof + (size_t)b0 * G * 8 : nullptr;
+            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP};
+            MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(G, nb_), dim3(1024), args, lds2_for(G), ctx->stream));
+        }
+        if (d_prof) {
+            std::vector<long long> h((size_t)batch * G * 8);
+            hipStreamSynchronize(ctx->stream);
+            hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
+            hipFree(d_prof);
+            double sp = 0, sr = 0, smn = 0, sl = 0, sb = 0;
+            for (int i = 0; i < batch * G; ++i) { sp += h[8 * i]; sr += h[8 * i + 1]; smn += h[8 * i + 2]; sl += h[8 * i + 3]; sb += h[8 * i + 4]; }
+            const double f = 0.01 / (batch * G) / (n - 1);     // 100 MHz ticks -> us per step
+            fprintf(stderr, "[tri_prof2] n=%d G=%d per step: poll %.2f us, prologue %.2f us, loop %.2f us, barrier %.2f us, tail %.2f us; shader clock %.0f MHz\n", n, G,
+                    sp * f, sr * f, sl * f, sb * f, smn * f, 100.0 * (double)h[5] / (double)(h[6] ? h[6] : 1));
+        }
+    } else if (persist) {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         if (!g_tri_attr2) {
             MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_persist, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
@@ -851,10 +1130,10 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             hipStreamSynchronize(ctx->stream);
             hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
             hipFree(d_prof);
-            double sp = 0, sr = 0, smn = 0, sl = 0, sb = 0;
-            for (int i = 0; i < batch * G; ++i) { sp += h[8 * i]; sr += h[8 * i + 1]; smn += h[8 * i + 2]; sl += h[8 * i + 3]; sb += h[8 * i + 4]; }
+            double sp = 0, sr = 0, smn = 0, sl = 0, sb = 0, s1 = 0, s2 = 0;
+            for (int i = 0; i < batch * G; ++i) { sp += h[8 * i]; sr += h[8 * i + 1]; smn += h[8 * i + 2]; sl += h[8 * i + 3]; sb += h[8 * i + 4]; s1 += h[8 * i + 5]; s2 += h[8 * i + 6]; }
             const double f = 0.01 / (batch * G) / (n - 1);     // 100 MHz ticks -> us per step
-            fprintf(stderr, "[tri_prof] n=%d G=%d RG=%d per step: poll %.2f us, prologue %.2f us, loop %.2f us, barrier %.2f us, tail %.2f us\n", n, G, RG, sp * f, sr * f, sl * f, sb * f, smn * f);
+            fprintf(stderr, "[tri_prof] n=%d G=%d RG=%d per step: poll %.2f us, prologue %.2f us (to barrier 2: %.2f, to barrier 3: %.2f), loop %.2f us, barrier %.2f us, tail %.2f us\n", n, G, RG, sp * f, sr * f, s1 * f, s2 * f, sl * f, sb * f, smn * f);
         }
     } else if (multi) {
         mopt_scope sc(ctx, "eigh_tridiag", n);
