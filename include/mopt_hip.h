@@ -93,6 +93,27 @@ int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, double *W, doubl
  * rsirfo.py:423,927,940; used internally to warm-start the eigen-solver from the previous eigenvectors). */
 int mopt_dgemm(mopt_ctx *ctx, int n, int batch, const double *A, const double *B, double *C);
 
+/* ---- nebmain's force-only optimizers (no Hessians) ------------------------------------------ */
+
+/* TR_NEB.TR_calc (multioptpy/Optimizer/trust_radius_neb.py:17-98): per image, clip `delta` to half the distance to the
+ * neighbour it moves towards, freeze it when force . delta < 0; end images: min(0.5, |delta|) or frozen when fixed.
+ * X, F ("total_force_list"), delta, move: I x N x 3 (bohr). */
+int mopt_neb_tr_calc(mopt_ctx *ctx, int I, int N, const double *X, const double *F, const double *delta, int fix_init,
+                     int fix_end, double *move);
+
+/* FIREOptimizer.optimize (multioptpy/Optimizer/fire_neb.py:38-92).  vel = total_velocity, pre_vel = pre_total_velocity (NULL
+ * when the reference's list is empty).  params = {FIRE_N_accelerate, FIRE_f_inc, FIRE_f_decelerate, FIRE_a_start,
+ * FIRE_dt_max}; state = {dt, a, n_reset}, in/out (the optimizer object's attributes).  Returns the new geometries in
+ * angstrom ((X + TR_calc(...)) * bohr2ang) and, in *dot_out (may be NULL), the band-wide sum of pre_vel . F. */
+int mopt_neb_fire(mopt_ctx *ctx, int I, int N, const double *X, const double *F, const double *vel, const double *pre_vel,
+                  int optimize_num, int fix_init, int fix_end, const double *params, double *state, double bohr2ang,
+                  double *new_geometry_ang, double *dot_out);
+
+/* SteepestDescentOptimizer.optimize (multioptpy/Optimizer/gradientdescent_neb.py:22-51): 0.5 * F clipped to half the
+ * neighbour distances; end images free or fixed. */
+int mopt_neb_sd(mopt_ctx *ctx, int I, int N, const double *X, const double *F, int fix_init, int fix_end, double bohr2ang,
+                double *new_geometry_ang);
+
 /* ---- callers around the step: CalculateMoveVector / TrustRadius / Kabsch ------------------ */
 
 /* TrustRadius.update_trust_radii's predicted energy change (multioptpy/Optimizer/trust_radius.py:146-151):

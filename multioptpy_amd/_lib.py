@@ -42,6 +42,9 @@ def _proto(lib):
     lib.mopt_quadratic_model.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, DP]
     lib.mopt_clip_and_move.argtypes = [vp, C.c_int, DP, DP, C.c_double, C.c_double, DP, DP, DP]
     lib.mopt_kabsch.argtypes = [vp, C.c_int, DP, DP, DP, DP]
+    lib.mopt_neb_tr_calc.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, C.c_int, C.c_int, DP]
+    lib.mopt_neb_fire.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, DP, C.c_int, C.c_int, C.c_int, DP, DP, C.c_double, DP, DP]
+    lib.mopt_neb_sd.argtypes = [vp, C.c_int, C.c_int, DP, DP, C.c_int, C.c_int, C.c_double, DP]
     lib.mopt_bneb_force.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, C.c_int, C.c_int, DP, DP]
     lib.mopt_neb_force.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, C.c_int, C.c_int, DP, DP]
     lib.mopt_rsirfo_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),

@@ -9,6 +9,7 @@
 #include <new>
 
 #include "pipeline.h"
+#include "neb_tr.cuh"
 
 namespace mopt {
 
@@ -88,31 +89,6 @@ __global__ void __launch_bounds__(256) k_rank1(int n, int first, const double *_
     const double tr = gam * t[r];
     double *row = H + ((size_t)loc * n + r) * n;
     for (int c = threadIdx.x & 31; c < n; c += 32) row[c] += tr * t[c];
-}
-
-struct TrIn { double r1, r2, c1, c2; };
-
-// TR_calc for one image given delta (trust_radius_neb.py:17-98).  Returns the scale applied to delta (0 = frozen).
-__device__ inline double tr_scale_edge(double nrm, bool fixed) {
-    if (fixed) return 0.0;
-    if (nrm < 1e-15) return 0.0;
-    return fmin(0.5, nrm) / nrm;
-}
-__device__ inline double tr_scale_interior(double dn, double r1, double r2, double c1, double c2, double fc) {
-    if (fc >= 0.0) {
-        if ((c1 > 0 && c2 < 0) || (c1 < 0 && c2 > 0)) {
-            if (dn > r1 && c1 > 0) return r1 / dn;
-            if (dn > r2 && c2 > 0) return r2 / dn;
-            return 1.0;
-        } else if (c1 < 0 && c2 < 0) {
-            return 1.0;
-        } else {
-            if (dn > r1) return r1 / dn;
-            if (dn > r2) return r2 / dn;
-            return 1.0;
-        }
-    }
-    return 0.0;
 }
 
 // grid = owned images, block 128, dynamic LDS: 2 * n doubles

@@ -148,14 +148,18 @@ def make_band(frames_ang, partition):
 
 
 def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
-                  ratio_of_rfo_step=0.5, quantise=True, record=None, device=None):
-    """Band relaxation with the Hessian-based branch of nebmain (`-fc`/`-modelhess`: RFOOptimizer on a BNEB force).
+                  ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999):
+    """Band relaxation as in nebmain: with FC_COUNT != -1 the Hessian-based branch (`-fc`: RFOOptimizer on a BNEB force),
+    otherwise the default FIRE optimizer, replaced by steepest descent from iteration `steepest_descent` on (`-sd`,
+    neb.py:794-804, 939-948).
     `engine.calculate(X_ang (I,N,3), optimize_num)` -> (E (I,), G (I,N,3), X_bohr (I,N,3), hessians | None) is the in-memory
     form of the reference's Engine.calculate and its tmp_hessian_i.npy side channel.  Per iteration, in the reference's order
     (neb.py:497-597): energies/gradients -> BNEB force -> RFOOptimizer.optimize (which recomputes the force, rfo_neb.py:131)
     -> edge fixing -> sequential Kabsch k -> k+1 (centres image k+1 in place) -> `%17.12f` quantisation."""
     from .MEP.pathopt_bneb_force import CaluculationBNEB
     from .Optimizer.rfo_neb import RFOOptimizer
+    from .Optimizer.fire_neb import FIREOptimizer
+    from .Optimizer.gradientdescent_neb import SteepestDescentOptimizer
 
     class _Config:
         pass
@@ -165,11 +169,17 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
     config.fix_init_edge = fixedges in (1,) or fixedges >= 3
     config.fix_end_edge = fixedges in (2,) or fixedges >= 3
     config.ratio_of_rfo_step = ratio_of_rfo_step
+    config.bohr2angstroms = BOHR2ANGSTROMS
+    config.apply_convergence_criteria = False
+    config.dt, config.a, config.n_reset = 0.5, 0.10, 0                      # NEBConfig defaults (neb.py:213-222)
+    config.FIRE_N_accelerate, config.FIRE_f_inc, config.FIRE_f_accelerate = 5, 1.10, 0.99
+    config.FIRE_f_decelerate, config.FIRE_a_start, config.FIRE_dt_max = 0.5, 0.1, 1.0
+    rfo_branch = FC_COUNT != -1
     geometry_ang = make_band(frames_ang, partition)
     if quantise:
         geometry_ang = np.array([quantise_xyz(x) for x in geometry_ang])
     STRING_FORCE_CALC = CaluculationBNEB(APPLY_CI_NEB)
-    optimizer = RFOOptimizer(config, persist_hessians=False, device=device)
+    optimizer = RFOOptimizer(config, persist_hessians=False, device=device) if rfo_branch else FIREOptimizer(config)
     tools = Calculationtools()
     pre_geom = pre_gradients = None
     pre_total_velocity = []
@@ -179,14 +189,20 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
         E = np.asarray(E, dtype="float64")
         G = np.asarray(G, dtype="float64")
         X = np.asarray(X, dtype="float64")
-        if hessians is not None:
+        if hessians is not None and rfo_branch:
             optimizer.set_image_hessians(hessians)
         if optimize_num == 0:
             init_geometry = X
         total_force = STRING_FORCE_CALC.calc_force(X, E, G, optimize_num, element_list)
         total_velocity = np.array(total_force, dtype="float64")            # NEB.force2velocity (neb.py:1159-1162)
-        new_geometry = np.array(optimizer.optimize(X, G, pre_geom, pre_gradients, optimize_num, E, E, pre_total_velocity,
-                                                   total_velocity, None, pre_geom, STRING_FORCE_CALC), dtype="float64")
+        if rfo_branch:
+            new_geometry = optimizer.optimize(X, G, pre_geom, pre_gradients, optimize_num, E, E, pre_total_velocity, total_velocity,
+                                              None, pre_geom, STRING_FORCE_CALC)
+        elif optimize_num < steepest_descent:
+            new_geometry = optimizer.optimize(X, total_force, pre_total_velocity, optimize_num, total_velocity, None, E, E, pre_geom)
+        else:
+            new_geometry = SteepestDescentOptimizer(config).optimize(X, total_force)
+        new_geometry = np.array(new_geometry, dtype="float64")
         opt_out = new_geometry.copy() if record is not None else None
         # NEB._apply_constraints (neb.py:966-998), no fixed atoms
         if config.fix_init_edge:
@@ -198,7 +214,8 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
             new_geometry[k] = copy.copy(aligned)
         if record is not None:
             record.append(dict(E=E.copy(), G=G.copy(), X=X.copy(), opt=opt_out, post=new_geometry.copy(),
-                               hess=[optimizer.get_image_hessian(i) for i in range(len(X))]))
+                               hess=[optimizer.get_image_hessian(i) for i in range(len(X))] if rfo_branch else [],
+                               fire=None if rfo_branch else (optimizer.dt, optimizer.a, optimizer.n_reset)))
         pre_geom, pre_gradients, pre_total_velocity = copy.copy(X), copy.copy(G), copy.copy(total_velocity)
         geometry_ang = np.array([quantise_xyz(x) for x in new_geometry]) if quantise else new_geometry
     return geometry_ang

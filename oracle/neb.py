@@ -242,6 +242,26 @@ class FIRE:
         return (X + np.array(mv)) * BOHR2ANG
 
 
+def steepest_descent(X, F, fix_init=False, fix_end=False):
+    """SteepestDescentOptimizer.optimize, gradientdescent_neb.py:22-51."""
+    X = np.asarray(X, dtype=float)
+    F = np.asarray(F, dtype=float)
+    delta = [0.5 * F[i] for i in range(len(F))]
+    mv = [delta[0] * 0.0 if fix_init else delta[0]]
+    for i in range(1, len(delta) - 1):
+        r1 = np.linalg.norm(X[i] - X[i - 1]) / 2.0
+        r2 = np.linalg.norm(X[i] - X[i + 1]) / 2.0
+        nrm = np.linalg.norm(delta[i])
+        if nrm > r1:
+            mv.append(delta[i] * r1 / nrm)
+        elif nrm > r2:
+            mv.append(delta[i] * r2 / nrm)
+        else:
+            mv.append(delta[i])
+    mv.append(delta[-1] * 0.0 if fix_end else delta[-1])
+    return (X + np.array(mv)) * BOHR2ANG
+
+
 def limit_step(mv, is_end):
     """rfo_neb.py:76-83."""
     nrm = np.linalg.norm(mv)

@@ -556,7 +556,7 @@ def _run_nebmain(tag, N, argv, out):
     from multioptpy.Calculator import lj_calculation_tools as ljt
     X = cases.band(8, N)
     cwd = os.getcwd()
-    calc_rec, opt_rec, post_rec = [], [], []
+    calc_rec, opt_rec, post_rec, fire_state = [], [], [], []
     with tempfile.TemporaryDirectory() as td:
         os.chdir(td)
         try:
@@ -568,7 +568,24 @@ def _run_nebmain(tag, N, argv, out):
                         f.write(f"Ar {r[0]:.10f} {r[1]:.10f} {r[2]:.10f}\n")
             parser = multioptpy.interface.init_parser()
             args = multioptpy.interface.nebparser(parser, ["ends", "-os", "lj"] + argv)
+            from multioptpy.Optimizer import fire_neb, gradientdescent_neb
             o_calc, o_opt, o_print = ljt.LJEngine.calculate, rfo_neb.RFOOptimizer.optimize, multioptpy.neb.NEB.print_geometry_list
+            o_fire, o_sd = fire_neb.FIREOptimizer.optimize, gradientdescent_neb.SteepestDescentOptimizer.optimize
+
+            nested = [0]          # RFOOptimizer.optimize runs a fresh FIREOptimizer inside (rfo_neb.py:187): not a driver-level call
+
+            def w_fire(self, geom, force, *rest):
+                o = o_fire(self, geom, force, *rest)
+                if not nested[0]:
+                    opt_rec.append((np.array(o, dtype=float), {}, {}))
+                    fire_state.append((self.dt, self.a, self.n_reset))
+                return o
+
+            def w_sd(self, geom, force, **kw):
+                o = o_sd(self, geom, force, **kw)
+                opt_rec.append((np.array(o, dtype=float), {}, {}))
+                fire_state.append((-1.0, -1.0, -1))
+                return o
 
             def w_calc(self, file_directory, optimize_num, pre_total_velocity, config):
                 r = o_calc(self, file_directory, optimize_num, pre_total_velocity, config)
@@ -580,7 +597,11 @@ def _run_nebmain(tag, N, argv, out):
                 hs = {}
                 for f in glob.glob(os.path.join(self.config.NEB_FOLDER_DIRECTORY, "tmp_hessian_*.npy")):
                     hs[int(os.path.basename(f)[len("tmp_hessian_"):-4])] = np.load(f)
-                o = o_opt(self, geom, grads, pre_geom, pre_grads, optimize_num, E, *rest)
+                nested[0] += 1
+                try:
+                    o = o_opt(self, geom, grads, pre_geom, pre_grads, optimize_num, E, *rest)
+                finally:
+                    nested[0] -= 1
                 hs_after = {}
                 for f in glob.glob(os.path.join(self.config.NEB_FOLDER_DIRECTORY, "tmp_hessian_*.npy")):
                     hs_after[int(os.path.basename(f)[len("tmp_hessian_"):-4])] = np.load(f)
@@ -592,12 +613,14 @@ def _run_nebmain(tag, N, argv, out):
                 return o_print(self, new_geometry, element_list, cm)
 
             ljt.LJEngine.calculate, rfo_neb.RFOOptimizer.optimize, multioptpy.neb.NEB.print_geometry_list = w_calc, w_opt, w_print
+            fire_neb.FIREOptimizer.optimize, gradientdescent_neb.SteepestDescentOptimizer.optimize = w_fire, w_sd
             try:
                 with quiet():
                     neb = multioptpy.neb.NEB(args)
                     neb.run()
             finally:
                 ljt.LJEngine.calculate, rfo_neb.RFOOptimizer.optimize, multioptpy.neb.NEB.print_geometry_list = o_calc, o_opt, o_print
+                fire_neb.FIREOptimizer.optimize, gradientdescent_neb.SteepestDescentOptimizer.optimize = o_fire, o_sd
         finally:
             os.chdir(cwd)
     nit = len(opt_rec)
@@ -609,6 +632,8 @@ def _run_nebmain(tag, N, argv, out):
         out[f"{tag}_i{k}_E"], out[f"{tag}_i{k}_G"], out[f"{tag}_i{k}_X"] = calc_rec[k]
         out[f"{tag}_i{k}_opt"] = opt_rec[k][0]
         out[f"{tag}_i{k}_post"] = post[k]
+        if fire_state:
+            out[f"{tag}_i{k}_fire"] = np.array(fire_state[k], dtype=float)
         for i, h in opt_rec[k][1].items():
             out[f"{tag}_i{k}_hin{i}"] = h
         for i, h in opt_rec[k][2].items():
@@ -621,6 +646,8 @@ def g8_nebmain():
     out = {}
     _run_nebmain("n", 7, ["-fc", "3", "-ns", "5", "-p", "5"], out)
     _run_nebmain("e", 7, ["-fc", "2", "-ns", "4", "-p", "5", "-fe", "3"], out)
+    _run_nebmain("f", 7, ["-ns", "9", "-p", "5"], out)                       # FIRE branch (the default optimizer of nebmain)
+    _run_nebmain("s", 7, ["-ns", "6", "-p", "5", "-sd", "3", "-fe", "1"], out)     # FIRE, then steepest descent from iteration 3
     np.savez_compressed(os.path.join(HERE, "g8_nebmain.npz"), **out)
 
 

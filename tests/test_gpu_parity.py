@@ -487,7 +487,7 @@ def test_optmain_driver_vs_reference(tag):
     print("optmain", tag, "worst move-vector deviation from the reference", worst)
 
 
-@pytest.mark.parametrize("tag", ["n", "e"])
+@pytest.mark.parametrize("tag", ["n", "e", "f", "s"])
 def test_nebmain_driver_vs_reference(tag):
     """a23: the in-memory nebmain iteration (RFO branch) on the device path against the reference driver's own band
     trajectory (G8): geometry read by the engine, optimizer output, geometry after edge fixing + Kabsch chain, Hessians."""
@@ -496,9 +496,33 @@ def test_nebmain_driver_vs_reference(tag):
     from multioptpy_amd import drivers
     from test_oracle_golden import _check_nebmain
 
-    def run(ends, fc, nstep, p, fe, rec):
+    def run(ends, fc, nstep, p, fe, rec, sd):
         eng = cases.LJEngine(FC_COUNT=fc, project=pj.project_hessian_trrot)           # the engine is upstream of the path
-        drivers.nebmain_steps(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec)
+        drivers.nebmain_steps(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, steepest_descent=sd)
 
     worst = _check_nebmain(run, np.load(os.path.join(G, "g8_nebmain.npz")), tag, 1e-8)
     print("nebmain", tag, "worst optimizer-output deviation from the reference", worst)
+
+
+def test_neb_tr_fire_standalone_vs_reference():
+    """a19: TR_NEB.TR_calc and FIREOptimizer.optimize as standalone drop-ins against the reference's outputs (G7)."""
+    from multioptpy_amd.Optimizer.trust_radius_neb import TR_NEB
+    from multioptpy_amd.Optimizer.fire_neb import FIREOptimizer
+    import cases
+    z = np.load(os.path.join(G, "g7_neb_step.npz"))
+    mv = TR_NEB().TR_calc(z["tr_X"], z["tr_F"], z["tr_delta"], None, None, None)
+    assert np.abs(np.array(mv) - z["tr_out"]).max() < 1e-12
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.NEB_FOLDER_DIRECTORY = None
+    cfg.fix_init_edge = cfg.fix_end_edge = cfg.apply_convergence_criteria = False
+    cfg.bohr2angstroms = cases.BOHR2ANG
+    cfg.dt, cfg.a, cfg.n_reset = 0.5, 0.10, 0
+    cfg.FIRE_N_accelerate, cfg.FIRE_f_inc, cfg.FIRE_f_accelerate = 5, 1.10, 0.99
+    cfg.FIRE_f_decelerate, cfg.FIRE_a_start, cfg.FIRE_dt_max = 0.5, 0.1, 1.0
+    fo = FIREOptimizer(cfg)
+    nx = fo.optimize(z["tr_X"], z["tr_F"], z["fire_prevel"], 3, z["fire_vel"], None, None, None, None)
+    assert np.abs(nx - z["fire_out"]).max() < 1e-12
+    assert np.allclose([fo.dt, fo.a, fo.n_reset], z["fire_state"], rtol=0, atol=1e-15)

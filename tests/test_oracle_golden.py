@@ -289,18 +289,21 @@ def test_g8_optmain_driver(tag):
 
 def _check_nebmain(run, z, tag, tol):
     argv = str(z[tag + "_argv"]).split()
-    fc = int(argv[argv.index("-fc") + 1])
+    fc = int(argv[argv.index("-fc") + 1]) if "-fc" in argv else -1
     nstep = int(argv[argv.index("-ns") + 1])
     p = int(argv[argv.index("-p") + 1])
     fe = int(argv[argv.index("-fe") + 1]) if "-fe" in argv else 0
+    sd = int(argv[argv.index("-sd") + 1]) if "-sd" in argv else 99999
     ends = z[tag + "_ends_bohr"] * cases.BOHR2ANG
     ends = np.array([[[float(f"{v:.10f}") for v in r] for r in x] for x in ends])       # the start files hold 10 decimals
     rec = []
-    run(ends, fc, nstep, p, fe, rec)
+    run(ends, fc, nstep, p, fe, rec, sd)
     assert len(rec) == int(z[tag + "_nit"])
     worst = 0.0
     for k, r in enumerate(rec):
         assert np.abs(r["X"] - z[f"{tag}_i{k}_X"]).max() < tol, (tag, k, "geometry read by the engine")
+        if f"{tag}_i{k}_fire" in z.files and r.get("fire") is not None and z[f"{tag}_i{k}_fire"][0] > 0:
+            assert np.allclose(r["fire"], z[f"{tag}_i{k}_fire"], rtol=0, atol=1e-14), (tag, k, "FIRE dt / a / n_reset")
         assert np.abs(r["E"] - z[f"{tag}_i{k}_E"]).max() < 1e-10, (tag, k, "energies")
         d = np.abs(r["opt"] - z[f"{tag}_i{k}_opt"]).max()
         worst = max(worst, d)
@@ -313,14 +316,15 @@ def _check_nebmain(run, z, tag, tol):
     return worst
 
 
-@pytest.mark.parametrize("tag", ["n", "e"])
+@pytest.mark.parametrize("tag", ["n", "e", "f", "s"])
 def test_g8_nebmain_driver(tag):
-    """a23: the oracle's in-memory nebmain iteration (RFO branch) against the reference driver's own band trajectory."""
+    """a23: the oracle's in-memory nebmain iteration (RFO branch; FIRE branch; FIRE then steepest descent) against the
+    reference driver's own band trajectory."""
     from oracle import driver
 
-    def run(ends, fc, nstep, p, fe, rec):
+    def run(ends, fc, nstep, p, fe, rec, sd):
         eng = cases.LJEngine(FC_COUNT=fc, project=pj.project_hessian_trrot)
-        driver.run_nebmain(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, literal=True)
+        driver.run_nebmain(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, literal=True, sd_from=sd)
 
     worst = _check_nebmain(run, np.load(os.path.join(G, "g8_nebmain.npz")), tag, 1e-9)
     print("nebmain", tag, "worst optimizer-output deviation", worst)
