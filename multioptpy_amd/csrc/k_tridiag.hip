@@ -738,19 +738,24 @@ __device__ __forceinline__ int sturm_count(const double *d, const double *e2, in
     return cnt;
 }
 
-// One workgroup per matrix.  Outputs: WT[n] eigenvalues (block by block, ascending inside a block), bstart[n]/bend[n] block
-// range of every index, cstart[] cluster start list (ncl[b] clusters), E zeroed at the split points, onenrm per index.
-// dynamic LDS: 3 n doubles + 2 n ints
-__global__ void __launch_bounds__(256) k_tri_bisect(int n, const double *__restrict__ D_, double *__restrict__ E_, double *__restrict__ WT_,
-                                                    int *__restrict__ bstart_, int *__restrict__ bend_, int *__restrict__ cstart_,
-                                                    int *__restrict__ ncl_, double *__restrict__ onenrm_) {
+// Eigenvalues by multi-section.  Workgroup (p, b) handles eigenvalues [64 p, 64 p + 64) of matrix b with 512 threads: the
+// 8 lanes of a group probe the 8 interior points of a nine-section of the current interval, each with its own Sturm
+// sequence, so a pass gains log2(9) = 3.17 bits and an eigenvalue takes 17 passes instead of the 53 of plain bisection --
+// the Sturm recurrence (one division per row) is an instruction-issue chain per lane, so lanes, not ILP, buy the speed, and
+// the 32 matrices alone would occupy 32 of the 256 CUs.  Every workgroup repeats the cheap splitting of the tridiagonal;
+// workgroup p = 0 writes the split off-diagonal and the block table.
+// Outputs: WT[n] eigenvalues (block by block, ascending inside a block), bstart[n]/bend[n] block range of every index,
+// E zeroed at the split points, onenrm per index.   dynamic LDS: 3 n doubles + 2 n ints
+constexpr int BIS_LANES = 8, BIS_THREADS = 512, BIS_PER_WG = BIS_THREADS / BIS_LANES;
+__global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double *__restrict__ D_, double *__restrict__ E_, double *__restrict__ WT_,
+                                                            int *__restrict__ bstart_, int *__restrict__ bend_, double *__restrict__ onenrm_) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *d = sm, *e = sm + n, *e2 = sm + 2 * n;
     int *bs = (int *)(sm + 3 * n), *be = bs + n;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.y, tid = threadIdx.x;
     const double *D = D_ + (size_t)b * n;
     double *E = E_ + (size_t)b * n, *WT = WT_ + (size_t)b * n, *onenrm = onenrm_ + (size_t)b * n;
-    int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n, *cstart = cstart_ + (size_t)b * n;
+    int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n;
     for (int i = tid; i < n; i += blockDim.x) { d[i] = D[i]; e[i] = (i < n - 1) ? E[i] : 0.0; }
     __syncthreads();
     // splitting.  dstebz drops e_i when e_i^2 <= ulp^2 |d_i d_{i+1}|; the Hessians of this path are often identity + low rank
@@ -765,48 +770,75 @@ __global__ void __launch_bounds__(256) k_tri_bisect(int n, const double *__restr
         } else e2[i] = 0.0;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += blockDim.x) { if (i < n - 1 && e2[i] == 0.0) e[i] = 0.0; E[i] = e[i]; }
-    __syncthreads();
     for (int i = tid; i < n; i += blockDim.x) {
+        if (i < n - 1 && e2[i] == 0.0) e[i] = 0.0;
         int s = i; while (s > 0 && e2[s - 1] != 0.0) --s;
         int t = i + 1; while (t < n && e2[t - 1] != 0.0) ++t;
-        bs[i] = s; be[i] = t; bstart[i] = s; bend[i] = t;
+        bs[i] = s; be[i] = t;
     }
     __syncthreads();
-    // eigenvalue j of its block by bisection
-    for (int j = tid; j < n; j += blockDim.x) {
-        const int s = bs[j], t = be[j], kk = j - s;
-        double nrm1 = 0.0;
-        if (t - s == 1) { WT[j] = d[s]; onenrm[j] = fabs(d[s]); continue; }
-        double gl = INFINITY, gu = -INFINITY, e2max = 0.0;
-        for (int i = s; i < t; ++i) {
-            const double lo_ = (i > s ? fabs(e[i - 1]) : 0.0), hi_ = (i < t - 1 ? fabs(e[i]) : 0.0);
-            gl = fmin(gl, d[i] - lo_ - hi_); gu = fmax(gu, d[i] + lo_ + hi_);
-            nrm1 = fmax(nrm1, fabs(d[i]) + lo_ + hi_);
-            if (i < t - 1) e2max = fmax(e2max, e2[i]);
-        }
-        const double pivmin = fmax(DTINY * fmax(1.0, e2max), DTINY);
-        const double bn = fmax(fabs(gl), fabs(gu));
-        gl -= 2.1 * bn * DEPS * (t - s) + 2.1 * pivmin; gu += 2.1 * bn * DEPS * (t - s) + 2.1 * pivmin;
-        double lo = gl, hi = gu;
-        for (int it = 0; it < 200; ++it) {
+    // (the split E is published by a separate tiny kernel: other workgroups of this matrix may still be reading E here)
+    if (blockIdx.x == 0) for (int i = tid; i < n; i += blockDim.x) { bstart[i] = bs[i]; bend[i] = be[i]; }
+    const int j = blockIdx.x * BIS_PER_WG + tid / BIS_LANES, sub = tid % BIS_LANES;
+    if (j >= n) return;
+    const int s = bs[j], t = be[j], kk = j - s;
+    if (t - s == 1) { if (sub == 0) { WT[j] = d[s]; onenrm[j] = fabs(d[s]); } return; }
+    double nrm1 = 0.0, gl = INFINITY, gu = -INFINITY, e2max = 0.0;
+    for (int i = s; i < t; ++i) {
+        const double lo_ = (i > s ? fabs(e[i - 1]) : 0.0), hi_ = (i < t - 1 ? fabs(e[i]) : 0.0);
+        gl = fmin(gl, d[i] - lo_ - hi_); gu = fmax(gu, d[i] + lo_ + hi_);
+        nrm1 = fmax(nrm1, fabs(d[i]) + lo_ + hi_);
+        if (i < t - 1) e2max = fmax(e2max, e2[i]);
+    }
+    const double pivmin = fmax(DTINY * fmax(1.0, e2max), DTINY);
+    const double bn = fmax(fabs(gl), fabs(gu));
+    gl -= 2.1 * bn * DEPS * (t - s) + 2.1 * pivmin; gu += 2.1 * bn * DEPS * (t - s) + 2.1 * pivmin;
+    double lo = gl, hi = gu;
+    const int shift = (threadIdx.x & 63) & ~(BIS_LANES - 1);          // first lane of this group inside its wave
+    for (int it = 0; it < 200; ++it) {
+        const double w9 = (hi - lo) / (BIS_LANES + 1);
+        const double x = lo + (sub + 1) * w9;
+        const double x0 = lo + w9;
+        if (!(x0 > lo && lo + BIS_LANES * w9 < hi && w9 > 0.0)) {       // interval too narrow for eight distinct probes: plain bisection
             const double mid = 0.5 * (lo + hi);
             if (!(mid > lo && mid < hi)) break;
             if (sturm_count(d, e2, s, t, mid, pivmin) > kk) hi = mid; else lo = mid;
-            if (hi - lo <= 2.0 * DEPS * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
+        } else {
+            const bool above = sturm_count(d, e2, s, t, x, pivmin) > kk;    // monotone in sub
+            const unsigned long long m = __ballot(above);
+            const unsigned g8 = (unsigned)((m >> shift) & 0xFFull);
+            const int f = g8 ? (__ffs((int)g8) - 1) : BIS_LANES;          // first probe with count > kk
+            const double nlo = (f == 0) ? lo : lo + f * w9;
+            const double nhi = (f == BIS_LANES) ? hi : lo + (f + 1) * w9;
+            lo = nlo; hi = nhi;
         }
-        WT[j] = 0.5 * (lo + hi);
-        onenrm[j] = nrm1;
+        if (hi - lo <= 2.0 * DEPS * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
     }
-    __threadfence_block();
+    if (sub == 0) { WT[j] = 0.5 * (lo + hi); onenrm[j] = nrm1; }
+}
+
+// After the bisection: publish the split off-diagonal and build the cluster table (dstein: a new cluster when
+// lambda_j - lambda_{j-1} > 1e-3 * ||T_block||_1).  One workgroup per matrix.  dynamic LDS: n ints
+__global__ void __launch_bounds__(256) k_tri_clusters(int n, const double *__restrict__ D_, double *__restrict__ E_, const double *__restrict__ WT_,
+                                                      const int *__restrict__ bstart_, const double *__restrict__ onenrm_,
+                                                      int *__restrict__ cstart_, int *__restrict__ ncl_) {
+    extern __shared__ __attribute__((aligned(16))) int flg[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *D = D_ + (size_t)b * n, *WT = WT_ + (size_t)b * n, *onenrm = onenrm_ + (size_t)b * n;
+    double *E = E_ + (size_t)b * n;
+    const int *bstart = bstart_ + (size_t)b * n;
+    int *cstart = cstart_ + (size_t)b * n;
+    for (int i = tid; i < n; i += blockDim.x) {
+        if (i < n - 1) {
+            const double ei = E[i];
+            if (fabs(ei) <= 32.0 * DEPS * (fabs(D[i]) + fabs(D[i + 1])) || fabs(ei) < DTINY) E[i] = 0.0;
+        } else E[i] = 0.0;
+        flg[i] = ((i == bstart[i]) || (fabs(WT[i] - WT[i - 1]) > 1e-3 * onenrm[i])) ? 1 : 0;
+    }
     __syncthreads();
-    // cluster table (dstein: a new cluster when lambda_j - lambda_{j-1} > 1e-3 * ||T_block||_1), serial compaction by one thread
     if (tid == 0) {
         int nc = 0;
-        for (int j = 0; j < n; ++j) {
-            const bool first = (j == bs[j]) || (fabs(WT[j] - WT[j - 1]) > 1e-3 * onenrm[j]);
-            if (first) cstart[nc++] = j;
-        }
+        for (int j = 0; j < n; ++j) if (flg[j]) cstart[nc++] = j;
         ncl_[b] = nc;
     }
 }
@@ -850,8 +882,10 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
                 if (xj - xjm < pertol) xj = xjm + pertol;
             }
             // ---- dlagtf: T - xj I = P L U   (serial, lane 0; arrays in LDS)
+            // operands by all lanes (coalesced); a serial walk over global memory by one lane costs a memory latency per element
+            for (int i = lane; i < m; i += WAVE) { a[i] = D[s + i] - xj; if (i < m - 1) { const double ei = E[s + i]; bb[i] = ei; c[i] = ei; } }
+            __syncthreads();
             if (lane == 0) {
-                for (int i = 0; i < m; ++i) { a[i] = D[s + i] - xj; if (i < m - 1) { bb[i] = E[s + i]; c[i] = E[s + i]; } }
                 double scale1 = fabs(a[0]) + fabs(bb[0]);
                 for (int k = 0; k < m - 1; ++k) {
                     const double scale2 = fabs(c[k]) + fabs(a[k + 1]) + ((k < m - 2) ? fabs(bb[k + 1]) : 0.0);
@@ -968,28 +1002,50 @@ __global__ void __launch_bounds__(256) k_tri_backtrans(int n, const double *__re
             const int i = lane + u * WAVE, j = j0 + q;
             z[q][u] = (j < n && i < n) ? Zt[(size_t)j * n + i] : 0.0;
         }
-    // reflector k acts on components k+1 .. n-1; applied in the order k = n-3 .. 0  (Q = H_0 H_1 ... H_{n-3})
+    // reflector k acts on components k+1 .. n-1; applied in the order k = n-3 .. 0  (Q = H_0 H_1 ... H_{n-3}).
+    // The reflector of the NEXT step is fetched from L2 into registers while the current one (in LDS) is applied, so the
+    // ~1 us load latency is off the per-step critical path.
+    constexpr int NLD = (64 * NPER + 255) / 256;
+    auto fetch = [&](int k, double (&r)[NLD]) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int i = tid + 256 * m;
+            double v = 0.0;
+            if (k >= 0) { if (i == k + 1) v = 1.0; else if (i > k + 1 && i < n) v = A[(size_t)k * n + i]; }
+            r[m] = v;
+        }
+    };
+    auto stage = [&](int buf, const double (&r)[NLD]) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) { const int i = tid + 256 * m; if (i < 64 * NPER) sv[buf][i] = r[m]; }
+    };
+    double pre[NLD];
+    fetch(n - 3, pre);
+    stage(0, pre);
+    double tau_next = (n >= 3) ? TAU[n - 3] : 0.0;
+    __syncthreads();
     int buf = 0;
     for (int k = n - 3; k >= 0; --k) {
-        // stage v_k (full length n, zero above k+1) through LDS
-        for (int i = tid; i < 64 * NPER; i += 256) {
-            double v = 0.0;
-            if (i == k + 1) v = 1.0; else if (i > k + 1 && i < n) v = A[(size_t)k * n + i];
-            sv[buf][i] = v;
-        }
-        __syncthreads();
-        const double tau = TAU[k];
+        fetch(k - 1, pre);                                     // in flight during the arithmetic below
+        const double tau = tau_next;
+        if (k >= 1) tau_next = TAU[k - 1];
         if (tau != 0.0) {
+            double dot[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                double dot = 0.0;
+                dot[q] = 0.0;
 #pragma unroll
-                for (int u = 0; u < NPER; ++u) dot += sv[buf][lane + u * WAVE] * z[q][u];
-                dot = wave_sum(dot) * tau;
-#pragma unroll
-                for (int u = 0; u < NPER; ++u) z[q][u] -= dot * sv[buf][lane + u * WAVE];
+                for (int u = 0; u < NPER; ++u) dot[q] += sv[buf][lane + u * WAVE] * z[q][u];
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dot[q] = wave_sum(dot[q]) * tau;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int u = 0; u < NPER; ++u) z[q][u] -= dot[q] * sv[buf][lane + u * WAVE];
         }
+        stage(buf ^ 1, pre);
+        __syncthreads();
         buf ^= 1;
     }
 #pragma unroll
@@ -1150,8 +1206,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     }
     {
         mopt_scope sc(ctx, "eigh_bisect", 1);
-        hipLaunchKernelGGL(k_tri_bisect, dim3(batch), dim3(256), (size_t)3 * n * 8 + (size_t)2 * n * 4, ctx->stream, n, d_D, d_E, d_WT,
-                           d_bstart, d_bend, d_cstart, d_ncl, d_onenrm);
+        hipLaunchKernelGGL(k_tri_bisect, dim3((n + BIS_PER_WG - 1) / BIS_PER_WG, batch), dim3(BIS_THREADS), (size_t)3 * n * 8 + (size_t)2 * n * 4,
+                           ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm);
+        hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)n * 4, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl);
     }
     {
         mopt_scope sc(ctx, "eigh_invit", 1);
