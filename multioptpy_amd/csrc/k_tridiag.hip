@@ -986,75 +986,102 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
 
 // ------------------------------------------------------------------------------------------------------------------
 // V = Q Z.  grid (ceil(n/16), batch), block 256 = 4 waves x 4 vectors; each lane keeps NPER slices of its 4 vectors.
-template <int NPER>
+// V = Q Z.  Lane mapping: a wave carries FOUR eigenvectors, 16 lanes each; lane part p of a vector owns the components
+// i = p + 16 u (u < NP16 = ceil(n / 16)).  The reflector dot product then needs only a 16-lane (one DPP row) reduction --
+// four DPP steps shared by the four vectors of the wave -- instead of one full-wave reduction per vector, which was most of
+// the instruction stream.  16 vectors per workgroup as before; the next reflector is fetched from L2 while the current one
+// (in LDS) is applied.
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_f64<0xB1, 0xF>(0.0, v);       // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(0.0, v);       // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141, 0xF>(0.0, v);      // row_half_mirror
+    v += dpp_f64<0x140, 0xF>(0.0, v);      // row_mirror: every lane of the 16-lane row holds the row's sum
+    return v;
+}
+
+template <int NP16, int BK>
 __global__ void __launch_bounds__(256) k_tri_backtrans(int n, const double *__restrict__ A_, const double *__restrict__ TAU_,
-                                                       double *__restrict__ Zt_) {
-    __shared__ double sv[2][64 * NPER];
+                                                       double *__restrict__ Zt_, int dbg) {
+    constexpr int LEN = 16 * NP16;                          // padded reflector length
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *sv0 = sm, *sv1 = sm + (size_t)BK * LEN;         // two blocks of BK reflectors
+    double *stau = sm + (size_t)2 * BK * LEN;               // [2][BK]
     const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6, tid = threadIdx.x;
+    const int part = lane & 15, vsub = lane >> 4;
     const double *A = A_ + (size_t)b * n * n, *TAU = TAU_ + (size_t)b * n;
     double *Zt = Zt_ + (size_t)b * n * n;
-    const int j0 = blockIdx.x * 16 + wid * 4;
-    double z[4][NPER];
+    const int j = blockIdx.x * 16 + wid * 4 + vsub;         // eigenvector of this 16-lane group
+    const long long c0 = (dbg & 32) ? clock64() : 0, w0 = (dbg & 32) ? wall_clock64() : 0;
+    double z[NP16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < NPER; ++u) {
-            const int i = lane + u * WAVE, j = j0 + q;
-            z[q][u] = (j < n && i < n) ? Zt[(size_t)j * n + i] : 0.0;
-        }
-    // reflector k acts on components k+1 .. n-1; applied in the order k = n-3 .. 0  (Q = H_0 H_1 ... H_{n-3}).
-    // The reflector of the NEXT step is fetched from L2 into registers while the current one (in LDS) is applied, so the
-    // ~1 us load latency is off the per-step critical path.
-    constexpr int NLD = (64 * NPER + 255) / 256;
-    auto fetch = [&](int k, double (&r)[NLD]) {
+    for (int u = 0; u < NP16; ++u) {
+        const int i = part + 16 * u;
+        z[u] = (j < n && i < n) ? Zt[(size_t)j * n + i] : 0.0;
+    }
+    // Reflectors are staged BK at a time: the global loads of the next block (one L2/MALL latency, ~1 us) are in flight
+    // while the current block is applied from LDS, and there is one barrier per block instead of one per reflector.
+    constexpr int NLD = (BK * LEN + 255) / 256;
+    // block kb covers reflectors k = kb, kb - 1, ..., kb - BK + 1 (slot c <-> k = kb - c)
+    auto fetch = [&](int kb, double (&r)[NLD], double &tv) {
 #pragma unroll
         for (int m = 0; m < NLD; ++m) {
-            const int i = tid + 256 * m;
+            const int e = tid + 256 * m, c = e / LEN, i = e - c * LEN, k = kb - c;
             double v = 0.0;
-            if (k >= 0) { if (i == k + 1) v = 1.0; else if (i > k + 1 && i < n) v = A[(size_t)k * n + i]; }
+            if (c < BK && k >= 0 && dbg != 2) { if (i == k + 1) v = 1.0; else if (i > k + 1 && i < n) v = A[(size_t)k * n + i]; }
             r[m] = v;
         }
+        tv = (tid < BK && kb - tid >= 0) ? TAU[kb - tid] : 0.0;
     };
-    auto stage = [&](int buf, const double (&r)[NLD]) {
+    auto stage = [&](int buf, const double (&r)[NLD], double tv) {
 #pragma unroll
-        for (int m = 0; m < NLD; ++m) { const int i = tid + 256 * m; if (i < 64 * NPER) sv[buf][i] = r[m]; }
+        for (int m = 0; m < NLD; ++m) { const int e = tid + 256 * m; if (e < BK * LEN) (buf ? sv1 : sv0)[e] = r[m]; }
+        if (tid < BK) stau[buf * BK + tid] = tv;
     };
-    double pre[NLD];
-    fetch(n - 3, pre);
-    stage(0, pre);
-    double tau_next = (n >= 3) ? TAU[n - 3] : 0.0;
+    // reflector k acts on components k+1 .. n-1; applied in the order k = n-3 .. 0  (Q = H_0 H_1 ... H_{n-3})
+    double pre[NLD], ptau;
+    fetch(n - 3, pre, ptau);
+    stage(0, pre, ptau);
     __syncthreads();
     int buf = 0;
-    for (int k = n - 3; k >= 0; --k) {
-        fetch(k - 1, pre);                                     // in flight during the arithmetic below
-        const double tau = tau_next;
-        if (k >= 1) tau_next = TAU[k - 1];
-        if (tau != 0.0) {
-            double dot[4];
+    for (int kb = n - 3; kb >= 0; kb -= BK) {
+        fetch(kb - BK, pre, ptau);                             // in flight during the arithmetic below
+        for (int c = 0; c < BK; ++c) {
+            const int k = kb - c;
+            if (k < 0) break;
+            const double tau = stau[buf * BK + c];
+            if (((dbg & 16) ? false : tau == 0.0) || dbg == 1) continue;
+            const double *v = (buf ? sv1 : sv0) + (size_t)c * LEN;
+            // all LDS reads first (pipelined), then the arithmetic from registers; components above the reflector's support
+            // hold zeros in LDS, so no per-chunk predicate (a predicate puts an LDS wait in front of every FMA)
+            double vv[NP16];
+            if (dbg & 8) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                dot[q] = 0.0;
+                for (int u = 0; u < NP16; ++u) vv[u] = 1e-3 * (u + part);
+            } else {
 #pragma unroll
-                for (int u = 0; u < NPER; ++u) dot[q] += sv[buf][lane + u * WAVE] * z[q][u];
+                for (int u = 0; u < NP16; ++u) vv[u] = v[part + 16 * u];
             }
+            double d4[4] = {0.0, 0.0, 0.0, 0.0};               // four independent chains: the FMA latency, not its issue rate, is the cost
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dot[q] = wave_sum(dot[q]) * tau;
+            for (int u = 0; u < NP16; ++u) d4[u & 3] = fma(vv[u], z[u], d4[u & 3]);
+            double dot = (d4[0] + d4[1]) + (d4[2] + d4[3]);
+            dot = ((dbg & 4) ? dot : row16_sum(dot)) * tau;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int u = 0; u < NPER; ++u) z[q][u] -= dot[q] * sv[buf][lane + u * WAVE];
+            for (int u = 0; u < NP16; ++u) z[u] = fma(-dot, vv[u], z[u]);
         }
-        stage(buf ^ 1, pre);
+        stage(buf ^ 1, pre, ptau);
         __syncthreads();
         buf ^= 1;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int u = 0; u < NPER; ++u) {
-            const int i = lane + u * WAVE, j = j0 + q;
-            if (j < n && i < n) Zt[(size_t)j * n + i] = z[q][u];
-        }
+    for (int u = 0; u < NP16; ++u) {
+        const int i = part + 16 * u;
+        if (j < n && i < n) Zt[(size_t)j * n + i] = z[u];
+    }
+    if ((dbg & 32) && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && (b == 0 || b == gridDim.y - 1)) {
+        const long long dc = clock64() - c0, dw = wall_clock64() - w0;
+        printf("[bt_prof] wg (%d,%d): start %lld, %.1f us, shader clock %.0f MHz\n", (int)blockIdx.x, b, w0 % 100000000LL, dw * 0.01, 100.0 * dc / (dw ? dw : 1));
+    }
 }
 
 // ascending sort of WT -> W, perm (same contract as k_jac_finalize); dynamic LDS npow2 * 12 bytes
@@ -1221,12 +1248,16 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     }
     {
         mopt_scope sc(ctx, "eigh_backtrans", 1);
-        const int nper = (n + 63) / 64;
+        const int np16 = (n + 15) / 16;
         const dim3 g((n + 15) / 16, batch);
-#define BT(NP) hipLaunchKernelGGL(k_tri_backtrans<NP>, g, dim3(256), 0, ctx->stream, n, d_A, d_TAU, d_Vt)
-        if (nper <= 1) BT(1); else if (nper <= 2) BT(2); else if (nper <= 3) BT(3); else if (nper <= 4) BT(4); else if (nper <= 5) BT(5);
-        else if (nper <= 6) BT(6); else if (nper <= 8) BT(8); else if (nper <= 10) BT(10); else if (nper <= 12) BT(12); else if (nper <= 16) BT(16);
-        else BT(24);
+        const int bt_dbg = getenv("MOPT_BT_DBG") ? atoi(getenv("MOPT_BT_DBG")) : 0;      // developer switch: 1 = no arithmetic, 2 = no reflector loads
+        // BK reflectors per staged block, chosen so that the two blocks stay near 20 KB of LDS: with 39 KB (BK = 8 at n = 300) only
+        // two workgroups fit a CU and the 608 workgroups of the headline band ran in two rounds (0.30 ms); BK = 4: one round, 0.24 ms
+#define BT(NP, BK) do { const size_t lds = ((size_t)2 * BK * 16 * NP + 2 * BK) * 8; \
+        hipLaunchKernelGGL((k_tri_backtrans<NP, BK>), g, dim3(256), lds, ctx->stream, n, d_A, d_TAU, d_Vt, bt_dbg); } while (0)
+        if (np16 <= 2) BT(2, 8); else if (np16 <= 4) BT(4, 8); else if (np16 <= 6) BT(6, 8); else if (np16 <= 8) BT(8, 8); else if (np16 <= 10) BT(10, 8);
+        else if (np16 <= 12) BT(12, 6); else if (np16 <= 14) BT(14, 5); else if (np16 <= 16) BT(16, 5); else if (np16 <= 19) BT(19, 4); else if (np16 <= 24) BT(24, 3);
+        else if (np16 <= 32) BT(32, 2); else if (np16 <= 40) BT(40, 2); else if (np16 <= 48) BT(48, 1); else if (np16 <= 64) BT(64, 1); else BT(96, 1);
 #undef BT
     }
     if (getenv("MOPT_TRI_INJECT_FAIL")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 1, sizeof(int), ctx->stream));   // test hook: matrix 0 fails
