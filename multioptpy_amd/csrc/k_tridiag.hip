@@ -748,7 +748,7 @@ __device__ __forceinline__ int sturm_count(const double *d, const double *e2, in
 // E zeroed at the split points, onenrm per index.   dynamic LDS: 3 n doubles + 2 n ints
 constexpr int BIS_LANES = 8, BIS_THREADS = 512, BIS_PER_WG = BIS_THREADS / BIS_LANES;
 __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double *__restrict__ D_, double *__restrict__ E_, double *__restrict__ WT_,
-                                                            int *__restrict__ bstart_, int *__restrict__ bend_, double *__restrict__ onenrm_) {
+                                                            int *__restrict__ bstart_, int *__restrict__ bend_, double *__restrict__ onenrm_, int small_max) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *d = sm, *e = sm + n, *e2 = sm + 2 * n;
     int *bs = (int *)(sm + 3 * n), *be = bs + n;
@@ -783,6 +783,7 @@ __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double 
     if (j >= n) return;
     const int s = bs[j], t = be[j], kk = j - s;
     if (t - s == 1) { if (sub == 0) { WT[j] = d[s]; onenrm[j] = fabs(d[s]); } return; }
+    if (t - s <= small_max) { if (sub == 0) onenrm[j] = 1.0; return; }           // solved whole by k_tri_small
     double nrm1 = 0.0, gl = INFINITY, gu = -INFINITY, e2max = 0.0;
     for (int i = s; i < t; ++i) {
         const double lo_ = (i > s ? fabs(e[i - 1]) : 0.0), hi_ = (i < t - 1 ? fabs(e[i]) : 0.0);
@@ -815,6 +816,95 @@ __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double 
         if (hi - lo <= 2.0 * DEPS * fmax(fabs(lo), fabs(hi)) + 2.0 * pivmin) break;
     }
     if (sub == 0) { WT[j] = 0.5 * (lo + hi); onenrm[j] = nrm1; }
+}
+
+// Small unreduced blocks (2 <= m <= TRI_SMALL) are solved whole by a one-sided Jacobi iteration, one wave per block: the
+// Hessians of this path (identity + low rank, rfo_neb.py:25) reduce to tridiagonals that split into blocks of 10-20 rows
+// holding 6-9-fold eigenvalue clusters; dstein has to walk such a cluster vector by vector (each against all previous ones),
+// which made one wave per cluster the critical path of the whole stage (100-200 us).  Jacobi does not care about
+// degeneracy: G = (T + sigma I) V is orthogonalised by plane rotations, m/2 disjoint column pairs per round on 4 lanes each
+// (round-robin tournament), eigenvalues are Rayleigh quotients, V is orthogonal by construction.
+constexpr int TRI_SMALL = 32;
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_f64<0xB1, 0xF>(0.0, v);       // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E, 0xF>(0.0, v);       // quad_perm [2,3,0,1]
+    return v;
+}
+// grid (n, batch): workgroup i works iff i is the first row of a small block.  Writes WT[s..t) and rows s..t-1 of Zt.
+__global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
+                                                  const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_,
+                                                  int *__restrict__ fail_) {
+    __shared__ double Gs[TRI_SMALL * TRI_SMALL], Vs[TRI_SMALL * TRI_SMALL];
+    __shared__ int s_rot;
+    const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;
+    const int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n;
+    if (bstart[i0] != i0) return;
+    const int s = i0, t = bend[i0], m = t - s;
+    if (m < 2 || m > TRI_SMALL) return;
+    const double *D = D_ + (size_t)b * n + s, *E = E_ + (size_t)b * n + s;
+    double *WT = WT_ + (size_t)b * n, *Zt = Zt_ + (size_t)b * n * n;
+    // sigma = 1.0625 ||T||_inf: T + sigma I is positive definite with condition number <= 33
+    double rs = 0.0;
+    if (lane < m) rs = fabs(D[lane]) + (lane > 0 ? fabs(E[lane - 1]) : 0.0) + (lane < m - 1 ? fabs(E[lane]) : 0.0);
+    const double nrm = wave_max(rs);
+    const double sigma = (nrm > 0.0) ? 1.0625 * nrm : 1.0;
+    for (int e = lane; e < m * m; e += WAVE) {
+        const int c = e / m, r = e - c * m;                  // column-major: column c, row r
+        double g = 0.0;
+        if (r == c) g = D[c] + sigma; else if (r == c + 1) g = E[c]; else if (r + 1 == c) g = E[r];
+        Gs[e] = g;
+        Vs[e] = (r == c) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    const int me = (m + 1) & ~1, npair = me >> 1;            // an odd block gets a bye
+    const int pi = lane >> 2, r4 = lane & 3;
+    bool converged = false;
+    for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
+        if (lane == 0) s_rot = 0;
+        __syncthreads();
+        for (int r = 0; r < me - 1; ++r) {
+            int p = -1, q = -1;
+            if (pi < npair) {
+                if (pi == 0) { p = me - 1; q = r; }
+                else { p = (r + pi) % (me - 1); q = (r - pi + (me - 1)) % (me - 1); }
+                if (p >= m || q >= m) { p = -1; q = -1; }           // the bye
+                else if (p > q) { const int tt = p; p = q; q = tt; }
+            }
+            double al = 0.0, be = 0.0, ga = 0.0;
+            if (p >= 0) {
+                const double *gp = Gs + p * m, *gq = Gs + q * m;
+                for (int k = r4; k < m; k += 4) { const double x = gp[k], y = gq[k]; al += x * x; be += y * y; ga += x * y; }
+            }
+            al = quad_sum(al); be = quad_sum(be); ga = quad_sum(ga);
+            if (p >= 0 && ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
+                const double zeta = (be - al) / (2.0 * ga);
+                const double tn = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / sqrt(1.0 + tn * tn), sn = c * tn;
+                double *gp = Gs + p * m, *gq = Gs + q * m, *vp = Vs + p * m, *vq = Vs + q * m;
+                for (int k = r4; k < m; k += 4) {
+                    const double x = gp[k], y = gq[k];
+                    gp[k] = c * x - sn * y; gq[k] = sn * x + c * y;
+                    const double u = vp[k], w = vq[k];
+                    vp[k] = c * u - sn * w; vq[k] = sn * u + c * w;
+                }
+                if (r4 == 0) atomicAdd(&s_rot, 1);
+            }
+            __syncthreads();
+        }
+        converged = (s_rot == 0);
+        __syncthreads();
+    }
+    if (!converged && lane == 0) atomicAdd(&fail_[b], 1);
+    // eigenpairs: column c -> eigenvalue v.g / v.v - sigma, eigenvector v / |v| into row s + c of Zt (zero outside the block)
+    for (int c = 0; c < m; ++c) {
+        double vg = 0.0, vv = 0.0;
+        if (lane < m) { const double v = Vs[c * m + lane]; vg = v * Gs[c * m + lane]; vv = v * v; }
+        vg = wave_sum(vg); vv = wave_sum(vv);
+        double *z = Zt + (size_t)(s + c) * n;
+        const double inv = 1.0 / sqrt(vv);
+        for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Vs[c * m + (i - s)] * inv : 0.0;
+        if (lane == 0) WT[s + c] = vg / vv - sigma;
+    }
 }
 
 // After the bisection: publish the split off-diagonal and build the cluster table (dstein: a new cluster when
@@ -855,9 +945,12 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
                                                         const double *__restrict__ WT_, const int *__restrict__ bstart_,
                                                         const int *__restrict__ bend_, const int *__restrict__ cstart_,
                                                         const int *__restrict__ ncl_, const double *__restrict__ onenrm_,
-                                                        double *__restrict__ Zt_, int *__restrict__ fail_, int extra) {
+                                                        double *__restrict__ Zt_, int *__restrict__ fail_, int extra, int dbg, int small_max) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const long long w0 = dbg ? wall_clock64() : 0;
+    long long tq_lu = 0, tq_sol = 0, tq_mgs = 0, tq_oth = 0, tq = 0;
+    int n_its = 0;
     const int gw = blockIdx.x, ngw = gridDim.x;
     double *base = sm;
     double *a = base, *bb = a + n, *c = bb + n, *dd = c + n, *x = dd + n;
@@ -870,6 +963,7 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
         const int j0 = cstart[ci];
         const int s = bstart[j0], t = bend[j0], m = t - s;
         const int j1 = (ci + 1 < nc && cstart[ci + 1] < t) ? cstart[ci + 1] : t;      // cluster = eigenvalues [j0, j1) of block [s, t)
+        if (m >= 2 && m <= small_max) continue;                                        // done by k_tri_small
         double xjm = 0.0;
         for (int j = j0; j < j1; ++j) {
             double *z = Zt + (size_t)j * n;
@@ -882,35 +976,46 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
                 if (xj - xjm < pertol) xj = xjm + pertol;
             }
             // ---- dlagtf: T - xj I = P L U   (serial, lane 0; arrays in LDS)
+            if (dbg) tq = wall_clock64();
             // operands by all lanes (coalesced); a serial walk over global memory by one lane costs a memory latency per element
             for (int i = lane; i < m; i += WAVE) { a[i] = D[s + i] - xj; if (i < m - 1) { const double ei = E[s + i]; bb[i] = ei; c[i] = ei; } }
             __syncthreads();
             if (lane == 0) {
-                double scale1 = fabs(a[0]) + fabs(bb[0]);
+                // The recurrence is carried in registers (a_k, b_k, scale1); the untouched entries it needs next (a_{k+2},
+                // e_{k+2}) are read one step ahead and the factors are only stored, never read back: a step costs its
+                // arithmetic chain instead of five dependent LDS round trips.
+                double ak = a[0], bk = bb[0];
+                double scale1 = fabs(ak) + fabs(bk);
+                double ck = c[0], an = a[1], bn = (m > 2) ? c[1] : 0.0;
                 for (int k = 0; k < m - 1; ++k) {
-                    const double scale2 = fabs(c[k]) + fabs(a[k + 1]) + ((k < m - 2) ? fabs(bb[k + 1]) : 0.0);
-                    if (c[k] == 0.0) {
-                        inn[k] = 0; scale1 = scale2;
-                        if (k < m - 2) dd[k] = 0.0;
+                    const double an_next = (k + 2 < m) ? a[k + 2] : 0.0, bn_next = (k + 2 < m - 1) ? c[k + 2] : 0.0;   // operands of step k + 1
+                    const double scale2 = fabs(ck) + fabs(an) + ((k < m - 2) ? fabs(bn) : 0.0);
+                    double a_out = ak, b_out = bk, c_out = ck, d_out = 0.0, ak1, bk1 = bn;
+                    int in_out = 0;
+                    if (ck == 0.0) {
+                        scale1 = scale2;
+                        ak1 = an;
+                    } else if (fabs(ck) * scale1 <= fabs(ak) * scale2) {
+                        // dlagtf compares piv2 = |c|/scale2 with piv1 = |a|/scale1; cross-multiplied (both scales > 0 here)
+                        scale1 = scale2;
+                        c_out = ck / ak;
+                        ak1 = an - c_out * bk;
                     } else {
-                        // dlagtf compares piv2 = |c|/scale2 with piv1 = |a|/scale1; cross-multiplied (both scales > 0 here):
-                        // two of the three divisions of the step disappear from the serial chain
-                        if (fabs(c[k]) * scale1 <= fabs(a[k]) * scale2) {
-                            inn[k] = 0; scale1 = scale2;
-                            c[k] = c[k] / a[k]; a[k + 1] -= c[k] * bb[k];
-                            if (k < m - 2) dd[k] = 0.0;
-                        } else {
-                            inn[k] = 1;
-                            const double mult = a[k] / c[k];
-                            a[k] = c[k];
-                            const double temp = a[k + 1];
-                            a[k + 1] = bb[k] - mult * temp;
-                            if (k < m - 2) { dd[k] = bb[k + 1]; bb[k + 1] = -mult * dd[k]; }
-                            bb[k] = temp; c[k] = mult;
-                        }
+                        in_out = 1;
+                        const double mult = ak / ck;
+                        a_out = ck;
+                        ak1 = bk - mult * an;
+                        if (k < m - 2) { d_out = bn; bk1 = -mult * bn; }
+                        b_out = an; c_out = mult;
                     }
+                    a[k] = a_out; bb[k] = b_out; c[k] = c_out; inn[k] = in_out;
+                    if (k < m - 2) dd[k] = d_out;
+                    ak = ak1; bk = bk1;
+                    ck = bn; an = an_next; bn = bn_next;               // e_{k+1} is both this step's b_{k+1} and the next step's c
                 }
+                a[m - 1] = ak;
             }
+            if (dbg) { const long long t = wall_clock64(); tq_lu += t - tq; tq = t; }
             unsigned long long seed = 0x9E3779B97F4A7C15ULL ^ ((unsigned long long)(j + 1) << 20);     // independent of the batch slot: shard == whole
             for (int i = lane; i < m; i += WAVE) { unsigned long long s2 = seed + 0x632BE59BD9B4E019ULL * (unsigned long long)(i + 1); lcg_uniform(s2); x[i] = lcg_uniform(s2); }
             __syncthreads();
@@ -926,19 +1031,32 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
                 const double scl = m * nrm1 * fmax(DEPS, fabs(a[m - 1])) / asum;
                 for (int i = lane; i < m; i += WAVE) x[i] *= scl;
                 __syncthreads();
+                if (dbg) { const long long t = wall_clock64(); tq_oth += t - tq; tq = t; ++n_its; }
                 // ---- dlagts (job = -1): solve with perturbation of tiny pivots (serial, lane 0)
                 if (lane == 0) {
-                    for (int k = 1; k < m; ++k) {
-                        if (inn[k - 1] == 0) x[k] -= c[k - 1] * x[k - 1];
-                        else { const double tmp = x[k - 1]; x[k - 1] = x[k]; x[k] = tmp - c[k - 1] * x[k]; }
+                    // forward: the running entry x_{k-1} stays in a register, operands of step k + 1 are read one step ahead
+                    {
+                        double xp = x[0];
+                        double xk = x[1], ck = c[0];
+                        int ik = inn[0];
+                        for (int k = 1; k < m; ++k) {
+                            const double xk_next = (k + 1 < m) ? x[k + 1] : 0.0, ck_next = (k + 1 < m) ? c[k] : 0.0;
+                            const int ik_next = (k + 1 < m) ? inn[k] : 0;
+                            if (ik == 0) { x[k - 1] = xp; xp = xk - ck * xp; }
+                            else { x[k - 1] = xk; xp = xp - ck * xk; }
+                            xk = xk_next; ck = ck_next; ik = ik_next;
+                        }
+                        x[m - 1] = xp;
                     }
+                    // backward: x_{k+1}, x_{k+2} in registers; a_k, b_k, d_k and the right-hand side of step k - 1 read ahead
                     const double bignum = 1.0 / DTINY;
+                    double x1 = 0.0, x2 = 0.0;
+                    double xr = x[m - 1], akk = a[m - 1], bkk = 0.0, dkk = 0.0;
                     for (int k = m - 1; k >= 0; --k) {
-                        double temp;
-                        if (k <= m - 3) temp = x[k] - bb[k] * x[k + 1] - dd[k] * x[k + 2];
-                        else if (k == m - 2) temp = x[k] - bb[k] * x[k + 1];
-                        else temp = x[k];
-                        double ak = a[k];
+                        const double xr_next = (k > 0) ? x[k - 1] : 0.0, ak_next = (k > 0) ? a[k - 1] : 1.0;
+                        const double bk_next = (k > 0) ? bb[k - 1] : 0.0, dk_next = (k > 0 && k - 1 <= m - 3) ? dd[k - 1] : 0.0;
+                        double temp = xr - bkk * x1 - dkk * x2;         // (bkk, dkk are zero where dlagts has no such term)
+                        double ak = akk;
                         double pert = (ak != 0.0) ? copysign(tol, ak) : tol;
                         for (int guard = 0; guard < 2000; ++guard) {
                             const double absak = fabs(ak);
@@ -950,11 +1068,31 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
                             }
                             break;
                         }
-                        x[k] = temp / ak;
+                        const double xv = temp / ak;
+                        x[k] = xv;
+                        x2 = x1; x1 = xv;
+                        xr = xr_next; akk = ak_next; bkk = bk_next; dkk = dk_next;
                     }
                 }
                 __syncthreads();
+                if (dbg) { const long long t = wall_clock64(); tq_sol += t - tq; tq = t; }
                 // ---- reorthogonalise inside the cluster (modified Gram-Schmidt against the finished vectors)
+                if (m <= WAVE) {
+                    // small block (the usual case: identity + low-rank Hessians split into blocks of 10-20): one component per
+                    // lane, the finished vectors of the cluster are fetched 16 at a time (one memory latency per 16 vectors instead
+                    // of one per vector), then applied in order from registers -- still modified Gram-Schmidt
+                    double xi = (lane < m) ? x[lane] : 0.0;
+                    for (int i2 = j0; i2 < j; i2 += 16) {
+                        double zr[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) zr[q] = (i2 + q < j && lane < m) ? Zt[(size_t)(i2 + q) * n + s + lane] : 0.0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            if (i2 + q < j) { const double dot = wave_sum(xi * zr[q]); xi -= dot * zr[q]; }
+                    }
+                    if (lane < m) x[lane] = xi;
+                    __syncthreads();
+                } else
                 for (int i2 = j0; i2 < j; ++i2) {
                     const double *zi = Zt + (size_t)i2 * n + s;
                     double dot = 0.0;
@@ -963,6 +1101,7 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
                     for (int i = lane; i < m; i += WAVE) x[i] -= dot * zi[i];
                     __syncthreads();
                 }
+                if (dbg) { const long long t = wall_clock64(); tq_mgs += t - tq; tq = t; }
                 double mx = 0.0;
                 for (int i = lane; i < m; i += WAVE) mx = fmax(mx, fabs(x[i]));
                 mx = wave_max(mx);
@@ -981,6 +1120,12 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
             __syncthreads();
             xjm = xj;
         }
+    }
+    if (dbg && lane == 0 && (wall_clock64() - w0) > 10000 && gw < nc) {
+        const int j0 = cstart[gw], s = bstart[j0], t = bend[j0];
+        const int j1 = (gw + 1 < nc && cstart[gw + 1] < t) ? cstart[gw + 1] : t;
+        printf("[invit_prof] wg (%d,%d): %.1f us, cluster of %d eigenvalues in a block of %d, lambda %.3e .. %.3e; LU %.1f, solves %.1f, MGS %.1f, other %.1f us, %d solves\n", (int)blockIdx.x, b,
+               (wall_clock64() - w0) * 0.01, j1 - j0, t - s, WT[j0], WT[j1 - 1], tq_lu * 0.01, tq_sol * 0.01, tq_mgs * 0.01, tq_oth * 0.01, n_its);
     }
 }
 
@@ -1231,10 +1376,15 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         hipLaunchKernelGGL(k_tridiag, dim3(batch), dim3(1024), (size_t)19 * n * 8, ctx->stream, n, getenv("MOPT_TRI_DBG") ? atoi(getenv("MOPT_TRI_DBG")) : 0, d_A, d_D, d_E, d_TAU);
     }
+    int small_max = getenv("MOPT_TRI_SMALL") ? atoi(getenv("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
+    if (small_max > TRI_SMALL) small_max = TRI_SMALL;
+    if (small_max < 0) small_max = 0;
     {
         mopt_scope sc(ctx, "eigh_bisect", 1);
         hipLaunchKernelGGL(k_tri_bisect, dim3((n + BIS_PER_WG - 1) / BIS_PER_WG, batch), dim3(BIS_THREADS), (size_t)3 * n * 8 + (size_t)2 * n * 4,
-                           ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm);
+                           ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm, small_max);
+        if (small_max > 0)
+            hipLaunchKernelGGL(k_tri_small, dim3(n, batch), dim3(64), 0, ctx->stream, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
         hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)n * 4, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl);
     }
     {
@@ -1244,7 +1394,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         // residuals unchanged at the 1e-14 level on every parity matrix, 0 is not: 1e-11), MOPT_INVIT_EXTRA overrides
         const int extra = getenv("MOPT_INVIT_EXTRA") ? atoi(getenv("MOPT_INVIT_EXTRA")) : 1;
         hipLaunchKernelGGL(k_tri_invit, dim3(n, batch), dim3(64), perwave, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_cstart,
-                           d_ncl, d_onenrm, d_Vt, d_fail, extra);
+                           d_ncl, d_onenrm, d_Vt, d_fail, extra, getenv("MOPT_INVIT_DBG") ? 1 : 0, small_max);
     }
     {
         mopt_scope sc(ctx, "eigh_backtrans", 1);
