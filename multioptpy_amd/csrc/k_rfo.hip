@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
                                                    const int *__restrict__ perm, const int *__restrict__ einfo,
                                                    const double *__restrict__ gt_all_, const double *__restrict__ Bg,
                                                    const double *__restrict__ Be, const UpdateCoef *__restrict__ coef,
-                                                   double *__restrict__ coef_out_) {
+                                                   double *__restrict__ coef_out_, int dbg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int b = blockIdx.x, lane = threadIdx.x;
     double *w0 = sm;             // [n] eigenvalues of the projected Hessian (ascending)
@@ -61,6 +61,8 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     int *vidx = (int *)(fac + n);        // [n] eigenvector (Vt row) of sorted position k
     int *kidx = vidx + n;                // [n] sorted position k of kept entry
     const WaveRed red;
+    const long long tp0 = dbg ? wall_clock64() : 0;
+    long long tp1 = 0, tp2 = 0, tp3 = 0;
     const mopt_rsirfo_params p = params[b];
     mopt_rsirfo_state st = states[b];
     const bool bad_eig = (einfo[2 * b + 1] & 1) != 0;
@@ -112,42 +114,77 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
         shifted2 = shifted;
     }
     st.level_shift_applied = shifted2 ? 1 : 0;
+    if (dbg) tp1 = wall_clock64();
     // --- ascending order of the image eigenvalues + 1e-6 filter (rsirfo.py:265-283,440)
     // rank of entry k among the starred values (stable); saddle_order is tiny so only those entries move.
+    // The reference sorts the image eigenvalues ascending (stable) and then drops |lambda*| < 1e-6.  The starred values
+    // differ from the ascending w0 only at the <= saddle_order reflected entries ("moved"), so the sorted position of every
+    // entry follows from prefix counts: computed by the whole wave with ballots (a serial walk by one lane cost 80 us here).
+    //   unmoved u at position c among the unmoved:  rank = c + #{moved t : val_t < val_u}
+    //   moved t (t-th in index order):               rank = #{unmoved u : val_u <= val_t} + #{t' < t : val_t' <= val_t} + #{t' > t : val_t' < val_t}
     int m = 0;
-    if (lane == 0) {
-        // serial merge: starred values differ from w0 only at <= saddle_order positions
-        int nmoved = 0;
-        int moved[8];
-        for (int i = 0; i < n && nmoved < 8; ++i) if (fac[i] != 1.0) moved[nmoved++] = i;
-        // collect unmoved in order, insert moved by value
-        int cnt = 0;
-        for (int i = 0; i < n; ++i) {
-            if (fac[i] != 1.0) continue;
-            kidx[cnt++] = i;
+    int *srt = kidx + n;                 // [n] index at sorted position
+    __shared__ int s_moved[8];
+    __shared__ int s_nmoved;
+    {
+        // moved entries, in index order (at most 8 are honoured, as before)
+        int off = 0;
+        for (int base = 0; base < n; base += WAVE) {
+            const int k = base + lane;
+            const bool f = (k < n) && (fac[k] != 1.0);
+            const unsigned long long mk = __ballot(f);
+            const int pos = off + __popcll(mk & ((1ull << lane) - 1ull));
+            if (f && pos < 8) s_moved[pos] = k;
+            off += __popcll(mk);
         }
+        if (lane == 0) s_nmoved = off < 8 ? off : 8;
+        __syncthreads();
+        const int nmoved = s_nmoved;
+        // unmoved entries
+        int offu = 0;
+        for (int base = 0; base < n; base += WAVE) {
+            const int k = base + lane;
+            const bool f = (k < n) && (fac[k] == 1.0);
+            const unsigned long long mk = __ballot(f);
+            if (f) {
+                int r = offu + __popcll(mk & ((1ull << lane) - 1ull));
+                const double val = w0[k];
+                for (int t = 0; t < nmoved; ++t) { const int i = s_moved[t]; if (fac[i] * w0[i] < val) ++r; }
+                srt[r] = k;
+            }
+            offu += __popcll(mk);
+        }
+        // moved entries (entries beyond the eighth moved one keep fac != 1 but are not placed, as in the serial form)
         for (int t = 0; t < nmoved; ++t) {
-            const int i = moved[t];
+            const int i = s_moved[t];
             const double val = fac[i] * w0[i];
-            int pos = cnt;
-            for (int c = 0; c < cnt; ++c) { if (fac[kidx[c]] * w0[kidx[c]] > val) { pos = c; break; } }
-            for (int c = cnt; c > pos; --c) kidx[c] = kidx[c - 1];
-            kidx[pos] = i;
-            ++cnt;
+            int cnt = 0;
+            for (int k = lane; k < n; k += WAVE) cnt += (fac[k] == 1.0 && w0[k] <= val) ? 1 : 0;
+            cnt = (int)(wave_sum((double)cnt) + 0.5);
+            for (int t2 = 0; t2 < nmoved; ++t2) {
+                if (t2 == t) continue;
+                const int i2 = s_moved[t2];
+                const double v2 = fac[i2] * w0[i2];
+                if (t2 < t ? (v2 <= val) : (v2 < val)) ++cnt;
+            }
+            if (lane == 0) srt[cnt] = i;
         }
-        // filter
-        int mm = 0;
-        for (int c = 0; c < n; ++c) {
-            const int i = kidx[c];
-            const double val = fac[i] * w0[i];
-            if (fabs(val) < p.small_eigval_thresh) continue;
-            kidx[mm++] = i;
+        __syncthreads();
+        const int ntot = offu + nmoved;
+        // filter, keeping the order
+        int offk = 0;
+        for (int base = 0; base < ntot; base += WAVE) {
+            const int c = base + lane;
+            bool f = false;
+            int i = 0;
+            if (c < ntot) { i = srt[c]; f = !(fabs(fac[i] * w0[i]) < p.small_eigval_thresh); }
+            const unsigned long long mk = __ballot(f);
+            if (f) kidx[offk + __popcll(mk & ((1ull << lane) - 1ull))] = i;
+            offk += __popcll(mk);
         }
-        best[0] = (double)mm;
+        m = offk;
+        __syncthreads();
     }
-    __syncthreads();
-    m = (int)best[0];
-    __syncthreads();
     for (int k = lane; k < m; k += WAVE) {
         const int i = kidx[k];
         ws[k] = fac[i] * w0[i];
@@ -156,11 +193,13 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     __syncthreads();
     st.prev_eigvec_size = m;
     st.n_kept = m;
+    if (dbg) tp2 = wall_clock64();
     // --- RS step (rsirfo.py:924-984)
     RsResult rr;
     rr.branch = 0; rr.alpha = p.alpha0; rr.lambda_aug0 = 0.0; rr.initial_norm = 0.0; rr.secular_iters0 = 0;
     if (m > 0) rr = rs_step(red, p, st.trust_radius, ws, gs, m, stp, best);
     __syncthreads();
+    if (dbg) tp3 = wall_clock64();
     // --- finite check (rsirfo.py:455-463) and steepest-descent fallback in the full eigenbasis
     double nonfinite = (m > 0) ? red.sum(m, [=](int k) { return isfinite(stp[k]) ? 0.0 : 1.0; }) : 0.0;
     for (int k = lane; k < n; k += WAVE) coef_out[k] = 0.0;
@@ -193,6 +232,9 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     st.jacobi_sweeps = (einfo[2 * b + 1] & 4) ? -1 : einfo[2 * b];       // -1: solver failure, surfaced as MOPT_E_NUMERIC
     st.hess_updated = coef ? coef[b].applied : 0;
     if (lane == 0) states[b] = st;
+    if (dbg && lane == 0 && (b == 0 || b == 15))
+        printf("[rfo_prof] image %d: setup %.1f us, order+filter %.1f us, rs_step %.1f us (branch %d, secular iters %d), rest %.1f us\n", b,
+               (tp1 - tp0) * 0.01, (tp2 - tp1) * 0.01, (tp3 - tp2) * 0.01, rr.branch, rr.secular_iters0, (wall_clock64() - tp3) * 0.01);
 }
 
 // out[b][j] = - sum_i coef[b][i] Vt[b][i][j]     grid (ceil(n/64), batch), block 256
@@ -229,14 +271,14 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
                     double *d_coefout, double *d_step) {
     using namespace mopt;
     mopt_scope sc(ctx, "rfo", 3);
-    const size_t lds = (size_t)7 * n * sizeof(double) + (size_t)2 * n * sizeof(int) + 16;
+    const size_t lds = (size_t)7 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
     if (!g_rfo_lds_attr_done) {
-        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
         g_rfo_lds_attr_done = 1;
     }
     hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_gp, d_einfo, d_gt_all);
     hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(64), lds, ctx->stream, n, d_params, d_states, d_W, d_perm, d_einfo,
-                       d_gt_all, d_Bg, d_Be, d_coef, d_coefout);
+                       d_gt_all, d_Bg, d_Be, d_coef, d_coefout, getenv("MOPT_RFO_DBG") ? 1 : 0);
     hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_coefout, d_einfo, d_step);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
