@@ -1294,6 +1294,13 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     int G2 = 8;
     auto lds2_for = [&](int G_) { return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(3 + 16) * n) * 8; };
     while (G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
+    // More workgroups per matrix when CUs are idle (few matrices per GPU) do not pay: measured at n = 300 with 4-16 matrices,
+    // G = 8 / 16 / 32 -> poll 1.9 / 2.8 / 4.5 us per step against 1.9 / 1.5 / 1.3 us for LDS pass + barrier.  MOPT_TRI_GMAX
+    // (default 8) raises the cap for experiments.
+    {
+        const int gmax = getenv("MOPT_TRI_GMAX") ? atoi(getenv("MOPT_TRI_GMAX")) : 8;
+        while (2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
+    }
     const bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && lds2_for(G2) <= (size_t)ctx->lds_limit - 4096 &&
                           G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 4 <= n;
     if (persist2) {
