@@ -1288,8 +1288,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     auto rows_for = [&](int G_) { const int nch = (n + TRI_RC - 1) / TRI_RC; return ((nch + G_ - 1) / G_) * TRI_RC; };
     auto lds_for = [&](int G_) { return ((size_t)rows_for(G_) * n + (size_t)(3 + RG) * n) * 8; };
     while (G < 256 && lds_for(G) > (size_t)ctx->lds_limit - 4096) G *= 2;
-    const bool persist = multi && !getenv("MOPT_TRI_NOPERSIST") && lds_for(G) <= (size_t)ctx->lds_limit - 4096 && G <= ctx->num_cu &&
-                         n <= 1024 && 4 * G + 4 <= n;
+    const bool persist = multi && getenv("MOPT_TRI_PERSIST1") && !getenv("MOPT_TRI_NOPERSIST") && lds_for(G) <= (size_t)ctx->lds_limit - 4096 &&
+                         G <= ctx->num_cu && n <= 1024 && 4 * G + 4 <= n;
     // row-per-wave variant (k_tri_persist2): 16 waves, accp[16][n]
     int G2 = 8;
     auto lds2_for = [&](int G_) { return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(3 + 16) * n) * 8; };
@@ -1301,8 +1301,18 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const int gmax = getenv("MOPT_TRI_GMAX") ? atoi(getenv("MOPT_TRI_GMAX")) : 8;
         while (2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
     }
-    const bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && lds2_for(G2) <= (size_t)ctx->lds_limit - 4096 &&
-                          G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 4 <= n;
+    bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && lds2_for(G2) <= (size_t)ctx->lds_limit - 4096 &&
+                    G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 4 <= n;
+    if (persist2 && !getenv("MOPT_TRI_FORCEPERSIST")) {
+        // Persistent kernel or one launch per Householder step?  Rough costs from the measurements in DESIGN.md section 5:
+        // persistent: (4 + G/4) us per step and per group of num_cu/G matrices (6.2 us at G = 8; the exchange grows with G);
+        // stepwise: all matrices at once, max(10 us, 40 % of the batch's bytes at 2.3 TB/s) per step (12 us at 32 x 300^2,
+        // 30 us at 64 x 600^2, where the persistent form would need G = 128 and 32 launches: 416 ms against 18 ms).
+        const int per_ = ctx->num_cu / G2;
+        const double t_persist = (double)((batch + per_ - 1) / per_) * (4.0 + 0.25 * G2);
+        const double t_step = fmax(10.0, (double)batch * n * n * 8.0 * 0.4 / 2.3e6);
+        if (t_step < t_persist) persist2 = false;
+    }
     if (persist2) {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         const int ch = (n + 63) / 64;

@@ -339,7 +339,7 @@ def test_rsprfo_traces_vs_reference():
     print("RSPRFO worst step deviation from the reference:", worst)
 
 
-@pytest.mark.parametrize("algo", ["tridiag", "jacobi"])
+@pytest.mark.parametrize("algo", ["tridiag", "jacobi", "tridiag-stepwise", "tridiag-persistent", "tridiag-nosmall"])
 def test_eigh_forced_route(ops, algo):
     """Both eigen-solvers forced for every size (MOPT_EIGH_ALGO): random, degenerate, clustered and LJ matrices.
     (By default the reduction route runs from n = 32 on and the Jacobi sweeps below.)"""
@@ -376,9 +376,17 @@ B = np.array([mats["lj22"], mats["projI"], mats["diag"]])
 w, v = ops.eigh(B)
 for b in range(3):
     assert np.abs(w[b] - np.linalg.eigvalsh(B[b])).max() < 1e-13 * max(1.0, np.abs(B[b]).sum(axis=1).max())
+# 40 matrices: more than the 32 groups of 8 workgroups that are resident at once (the persistent kernel is launched twice)
+B = np.array([mats["lj22"] + 0.01 * k * np.eye(66) for k in range(40)])
+w, v = ops.eigh(B)
+for b in range(40):
+    assert np.abs(w[b] - np.linalg.eigvalsh(B[b])).max() < 1e-13 * max(1.0, np.abs(B[b]).sum(axis=1).max())
+    assert np.abs(v[b].T @ v[b] - np.eye(66)).max() < 1e-11
 sys.exit(bad)
 '''
-    env = dict(os.environ, MOPT_EIGH_ALGO=algo)
+    extra = {"tridiag-stepwise": {"MOPT_TRI_NOPERSIST": "1"}, "tridiag-persistent": {"MOPT_TRI_FORCEPERSIST": "1"},
+             "tridiag-nosmall": {"MOPT_TRI_SMALL": "0"}}.get(algo, {})
+    env = dict(os.environ, MOPT_EIGH_ALGO=algo.split("-")[0], **extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     print(r.stdout)
     print(r.stderr[-2000:])
