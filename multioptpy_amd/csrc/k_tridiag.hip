@@ -503,7 +503,8 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     const long long c_start = prof ? clock64() : 0, w_start = prof ? wall_clock64() : 0;
     double *sva = sm, *sw = sm + n, *svb = sm + 2 * n;      // reflector ping-pong (sva/svb), w
     double *accp = sm + 3 * n;                              // [NW][n] partial SYMV per wave
-    double *Aloc = sm + (size_t)(3 + NW) * n;               // [rows_cap][n] rows owned by this workgroup
+    double *sps = sm + (size_t)(3 + NW) * n, *srow = sps + n;     // collected partial sums and pivot-row entries per column
+    double *Aloc = sm + (size_t)(5 + NW) * n;               // [rows_cap][ns] rows owned by this workgroup
     const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const int j = tid, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw0 = (n + 63) >> 6;                           // waves that carry columns in the prologue
@@ -583,6 +584,76 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
 #ifndef MOPT_P2_GUARD
 #define MOPT_P2_GUARD 0
 #endif
+#ifndef MOPT_P2_W0
+#define MOPT_P2_W0 1
+#endif
+#if MOPT_P2_W0
+        // Single-wave prologue: the column threads only deposit what they collected (sum of the partials, row entry) in LDS;
+        // after ONE barrier wave 0 alone forms w_k and the reflector of step k+1 with its lanes striding the columns (CH per
+        // lane, all in registers, reductions by DPP only) while the other 15 waves wait at the next barrier.  The same
+        // ~250-instruction dependent stream then issues from one wave instead of sharing each SIMD with three idle copies.
+        double *red2 = red + 32;
+        if (mine) { sps[j] = psum; srow[j] = rowj; }
+        lds_barrier();
+        if (s_fail) break;
+        if (wid == 0) {
+            const double v_lo = sv[lo];
+            double vq[CH], wq[CH], rq[CH];
+            double pvl = 0.0;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                const bool mq = (jj >= lo && jj < n);
+                vq[q] = mq ? sv[jj] : 0.0;
+                wq[q] = (mq && k >= 0) ? tau * sps[jj] : 0.0;                  // p_j
+                rq[q] = mq ? srow[jj] : 0.0;
+                pvl = fma(wq[q], vq[q], pvl);
+            }
+            double w_lo = 0.0;
+            if (k >= 0) {
+                const double c = -0.5 * tau * wave_sum(pvl);
+                w_lo = tau * sps[lo] + c * v_lo;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int jj = lane + 64 * q;
+                    wq[q] = fma(c, vq[q], wq[q]);                              // w_j = p_j + c v_j
+                    if (jj >= lo && jj < n) sw[jj] = wq[q];
+                }
+            }
+            double xl = 0.0;
+            const bool upd = (k >= 0 && tau != 0.0);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                if (upd) rq[q] -= v_lo * wq[q] + w_lo * vq[q];
+                if (jj >= lo + 2 && jj < n) xl = fma(rq[q], rq[q], xl);
+                if (jj == lo + 1) red2[16] = rq[q];
+                if (jj == lo) red2[17] = rq[q];
+            }
+            const double xn2 = wave_sum(xl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // red2[16], red2[17] written by this wave
+            const double alpha = (lo + 1 < n) ? red2[16] : 0.0;
+            const double diag = red2[17];
+            double scal = 0.0, betan = alpha;
+            taun = 0.0;
+            if (nk <= n - 3 && xn2 != 0.0) {
+                betan = -copysign(sqrt(alpha * alpha + xn2), alpha);
+                taun = (betan - alpha) / betan;
+                scal = 1.0 / (alpha - betan);
+            }
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                if (jj >= lo && jj < n) svn[jj] = (jj == lo) ? 0.0 : (jj == lo + 1) ? 1.0 : rq[q] * scal;
+            }
+            if (lane == 0) {
+                red2[20] = taun;
+                if (g == 0) { D[nk] = diag; E[nk] = betan; TAU[nk] = taun; if (nk == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; } }
+            }
+        }
+        lds_barrier();                                      // sw, svn, tau' complete
+        if (wid != 0) taun = red2[20];
+#else
         const bool cw = MOPT_P2_CW ? (wid < nw0) : true;
         double wj_own = 0.0, w_lo = 0.0, v_own = 0.0, v_lo = 0.0;
         if (cw) { v_own = mine ? sv[j] : 0.0; v_lo = sv[lo]; }
@@ -637,6 +708,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
         }
         lds_barrier();                                      // sw, svn, tau' complete
         if (!cw) taun = red2[20];
+#endif
         if (k >= 0 && g == 0 && j >= k + 2 && j < n) A[(size_t)k * n + j] = sv[j];   // reflector k, dsytrd layout
         if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
         // ---- main pass: rank-2 update of the live rows with (v, w), partial SYMV with v'
@@ -1292,7 +1364,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                          G <= ctx->num_cu && n <= 1024 && 4 * G + 4 <= n;
     // row-per-wave variant (k_tri_persist2): 16 waves, accp[16][n]
     int G2 = 8;
-    auto lds2_for = [&](int G_) { return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(3 + 16) * n) * 8; };
+    auto lds2_for = [&](int G_) { return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(5 + 16) * n) * 8; };
     while (G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
     // More workgroups per matrix when CUs are idle (few matrices per GPU) do not pay: measured at n = 300 with 4-16 matrices,
     // G = 8 / 16 / 32 -> poll 1.9 / 2.8 / 4.5 us per step against 1.9 / 1.5 / 1.3 us for LDS pass + barrier.  MOPT_TRI_GMAX
