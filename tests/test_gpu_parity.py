@@ -534,3 +534,62 @@ def test_neb_tr_fire_standalone_vs_reference():
     nx = fo.optimize(z["tr_X"], z["tr_F"], z["fire_prevel"], 3, z["fire_vel"], None, None, None, None)
     assert np.abs(nx - z["fire_out"]).max() < 1e-12
     assert np.allclose([fo.dt, fo.a, fo.n_reset], z["fire_state"], rtol=0, atol=1e-15)
+
+
+def _oracle_band_steps(X0, nsteps, literal=False, hessians=None):
+    """The oracle's RFO-NEB loop on the LJ surface: yields (X, E, G, newX_angstrom) per step."""
+    from oracle import neb as oneb
+    I, N = X0.shape[0], X0.shape[1]
+    calc = oneb.BNEB(literal=literal)
+    opt = oneb.RFONEB([None] * I if hessians is None else hessians, literal=literal)
+    X = X0.copy()
+    preX = preG = None
+    pre_vel = []
+    for it in range(nsteps):
+        E = np.zeros(I)
+        Gr = np.zeros((I, N, 3))
+        for i in range(I):
+            E[i], Gr[i] = cases.lj(X[i])[:2]
+        F = calc.calc_force(X, E, Gr, it, None)
+        newX = np.array(opt.optimize(X, Gr, preX, preG, it, E, pre_vel, np.array(F), calc))
+        yield X, E, Gr, newX
+        preX, preG, pre_vel = X.copy(), Gr.copy(), np.array(F)
+        X = newX / cases.BOHR2ANG
+
+
+def test_band_headline_size_vs_oracle():
+    """The BASELINE headline size, 32 images x 100 atoms (n = 300): three consecutive band steps against the oracle on the
+    same inputs (the oracle itself is pinned by the reference's goldens at I = 8, N = 7)."""
+    from multioptpy_amd.band import Band
+    I, N = 32, 100
+    band = Band(I, N)
+    worst = 0.0
+    for it, (X, E, Gr, ref) in enumerate(_oracle_band_steps(cases.band(I, N), 3)):
+        band.upload(X, E, Gr)
+        band.step(it)
+        newX, _ = band.download(want_force=True)
+        err = np.abs(newX - ref).max()
+        worst = max(worst, err)
+        assert err < 1e-8, (it, err)
+    band.close()
+    print("32 x 100 band: worst deviation from the oracle", worst, "angstrom")
+
+
+@pytest.mark.parametrize("shape", [(3, 3), (4, 5), (3, 5), (3, 4), (9, 3)])
+def test_band_tiny_shapes_vs_oracle(shape):
+    """Small band shapes: one interior image (the smallest band the C ABI accepts is I = 3), triatomics (n = 9: three internal
+    degrees of freedom).  (Diatomics are left out on purpose: there the reference's gradient projection takes a full 6 x 6
+    orthogonal Q, the projected gradient is rounding noise (1e-23) and RSIRFO rescales that noise to the trust radius --
+    the reference's own result is not reproducible to any tolerance.)"""
+    from multioptpy_amd.band import Band
+    I, N = shape
+    rng = np.random.default_rng(100 * I + N)
+    base = rng.normal(size=(N, 3)) * 4.0 + np.arange(N)[:, None] * 6.0
+    X0 = np.array([base + 0.15 * i * rng.normal(size=(N, 3)) for i in range(I)])
+    band = Band(I, N)
+    for it, (X, E, Gr, ref) in enumerate(_oracle_band_steps(X0, 3, literal=False)):
+        band.upload(X, E, Gr)
+        band.step(it)
+        newX, _ = band.download(want_force=True)
+        assert np.abs(newX - ref).max() < 1e-8, (shape, it, np.abs(newX - ref).max())
+    band.close()
