@@ -491,7 +491,10 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
 // broadcast) instead of once per row and column wave, and the per-column operands w_j, v_j and the SYMV partials stay in
 // registers.  The 16 per-wave partial vectors meet in LDS (accp[16][n]); thread j < n adds them in wave order.
 // The prologue (poll, w_k, reflector k+1) runs on the threads tid = column j < n exactly as in k_tri_persist.
-template <int CH>
+// TR > 0: register-resident variant -- wave w owns the local rows w, w + 16, ..., w + 16 (TR - 1) for the whole reduction and
+// keeps them in registers (TR x CH doubles per lane), so the main pass has no LDS traffic for the matrix at all (LDS stores
+// run at ~85 B/clk per CU and were the pass's limit) and LDS only holds the vectors.  TR = 0: rows in LDS (any size that fits).
+template <int CH, int TR>
 __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_cap, double *__restrict__ A_, double *__restrict__ D_,
                                                        double *__restrict__ E_, double *__restrict__ TAU_, u64 *__restrict__ XCH_,
                                                        size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof) {
@@ -517,13 +520,30 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     for (int i = tid; i < 3 * n; i += blockDim.x) sm[i] = 0.0;   // v, w, v': the branch-free main pass multiplies them by zero at k = -1
     int r_end = 0;                                           // local rows that exist (global index < n)
     for (int r = 0; r < rows_cap; ++r) r_end += ((g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC) < n) ? 1 : 0;
-    for (int r = wid; r < r_end; r += NW) {
-        const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+    constexpr int TRR = TR > 0 ? TR : 1;
+    double areg[TRR][CH];                                    // (TR > 0) the rows of this wave
+    if constexpr (TR > 0) {
 #pragma unroll
-        for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) Aloc[r * ns + jj] = (jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
+        for (int t = 0; t < TR; ++t) {
+            const int r = wid + NW * t;
+            const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; areg[t][q] = (r < r_end && jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
+        }
+        __syncthreads();
+        if (g == 0 && wid == 0) {                            // row 0 (local row 0 of workgroup 0): tag 1 in buffer 1 (step k = -1)
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) ll_put(&ROWX[((size_t)1 * n + jj) * 2], areg[0][q], 1u); }
+        }
+    } else {
+        for (int r = wid; r < r_end; r += NW) {
+            const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) Aloc[r * ns + jj] = (jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
+        }
+        __syncthreads();
+        if (g == 0 && j < n) ll_put(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u);     // row 0: tag 1 in buffer 1 (step k = -1)
     }
-    __syncthreads();
-    if (g == 0 && j < n) ll_put(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u);     // row 0: tag 1 in buffer 1 (step k = -1)
     double tau = 0.0, taun = 0.0;
     double *sv = sva, *svn = svb;
     for (int k = -1; k <= n - 3; ++k) {
@@ -738,6 +758,29 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
                 acc[q] = 0.0; wj[q] = 0.0; vj[q] = 0.0;
                 if (wid < nact && q >= q0g && q < chn && do_upd) { wj[q] = cl ? sw[jj] : 0.0; vj[q] = cl ? sv[jj] : 0.0; }
             }
+            if constexpr (TR > 0) {
+                (void)r_first; (void)own_next; (void)q0g;
+#pragma unroll
+                for (int t = 0; t < TR; ++t) {
+                    const int r = wid + NW * t;
+                    const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+                    if (r < r_end && gi > lo) {                                       // wave-uniform
+                        const double vi = -sv[gi], wi = -sw[gi], zi = do_mv ? svn[gi] : 0.0;      // LDS broadcasts
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) {
+                            areg[t][q] = fma(vi, wj[q], areg[t][q]);
+                            areg[t][q] = fma(wi, vj[q], areg[t][q]);
+                            acc[q] = fma(areg[t][q], zi, acc[q]);
+                        }
+                        if (gi == lo + 1) {                                             // the next pivot row: publish it
+#pragma unroll
+                            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put(&ROWn[(size_t)jj * 2], areg[t][q], tag + 1u); }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) accp[wid * n + jj] = acc[q]; }
+            } else {
             for (int rr = r_first + wid; rr < r_end; rr += NW) {
                 const int gi = (g + (rr / TRI_RC) * G) * TRI_RC + (rr % TRI_RC);
                 const double vi = -sv[gi], wi = -sw[gi], zi = do_mv ? svn[gi] : 0.0;          // LDS broadcasts
@@ -764,6 +807,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
                 for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put(&ROWn[(size_t)jj * 2], Ar[jj], tag + 1u); }
             }
         }
+            }
         if (prof) { t1 = wall_clock64(); t_loop += t1 - t0; t0 = t1; }
         lds_barrier();
         if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
@@ -782,9 +826,17 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     {
         const int gi_last = n - 1;
         const int c = gi_last / TRI_RC;
-        if (c % G == g && tid == 0 && !s_fail) {
+        if (c % G == g && !s_fail) {
             const int r = (c / G) * TRI_RC + (gi_last % TRI_RC);
-            D[n - 1] = Aloc[r * ns + (n - 1)];
+            if constexpr (TR > 0) {
+#pragma unroll
+                for (int t = 0; t < TR; ++t)
+#pragma unroll
+                    for (int q = 0; q < CH; ++q)
+                        if (r == wid + NW * t && (n - 1) == lane + 64 * q) D[n - 1] = areg[t][q];
+            } else if (tid == 0) {
+                D[n - 1] = Aloc[r * ns + (n - 1)];
+            }
         }
     }
 }
@@ -1389,10 +1441,30 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         const int ch = (n + 63) / 64;
         const void *fn = nullptr;
-#define P2(C) ((const void *)k_tri_persist2<C>)
+#define P2(C) ((const void *)k_tri_persist2<C, 0>)
         fn = ch <= 1 ? P2(1) : ch <= 2 ? P2(2) : ch <= 3 ? P2(3) : ch <= 4 ? P2(4) : ch <= 5 ? P2(5) : ch <= 6 ? P2(6) : ch <= 8 ? P2(8)
            : ch <= 10 ? P2(10) : ch <= 12 ? P2(12) : P2(16);
 #undef P2
+        // register-resident rows when the tile per lane is small enough: TR rows x CH chunks <= 16 doubles
+        const int tr = (rows_for(G2) + 15) / 16;
+        size_t lds_use = lds2_for(G2);
+        if (!getenv("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
+            const int chs = ch <= 6 ? ch : 8;
+#define P3(C, T) ((const void *)k_tri_persist2<C, T>)
+#define P3T(C) (tr == 1 ? P3(C, 1) : tr == 2 ? P3(C, 2) : P3(C, 3))
+            const void *f3 = nullptr;
+            switch (chs) {
+                case 2: f3 = P3T(2); break;
+                case 3: f3 = P3T(3); break;
+                case 4: f3 = P3T(4); break;
+                case 5: f3 = P3T(5); break;
+                case 6: f3 = (tr <= 2) ? (tr == 1 ? P3(6, 1) : P3(6, 2)) : nullptr; break;
+                case 8: f3 = (tr <= 2) ? (tr == 1 ? P3(8, 1) : P3(8, 2)) : nullptr; break;
+            }
+#undef P3T
+#undef P3
+            if (f3) { fn = f3; lds_use = (size_t)(5 + 16) * n * 8; }
+        }
         MOPT_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
         const int G = G2;
         int rows = rows_for(G);
@@ -1410,7 +1482,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             int *pF = d_fail + b0;
             long long *pP = d_prof ? d_prof + (size_t)b0 * G * 8 : nullptr;
             void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP};
-            MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(G, nb_), dim3(1024), args, lds2_for(G), ctx->stream));
+            MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(G, nb_), dim3(1024), args, lds_use, ctx->stream));
         }
         if (d_prof) {
             std::vector<long long> h((size_t)batch * G * 8);
