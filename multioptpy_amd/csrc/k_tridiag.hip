@@ -640,20 +640,19 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
                     if (jj >= lo && jj < n) sw[jj] = wq[q];
                 }
             }
-            double xl = 0.0;
+            double xl = 0.0, al_l = 0.0, dg_l = 0.0;
             const bool upd = (k >= 0 && tau != 0.0);
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
                 const int jj = lane + 64 * q;
                 if (upd) rq[q] -= v_lo * wq[q] + w_lo * vq[q];
                 if (jj >= lo + 2 && jj < n) xl = fma(rq[q], rq[q], xl);
-                if (jj == lo + 1) red2[16] = rq[q];
-                if (jj == lo) red2[17] = rq[q];
+                if (jj == lo + 1) al_l = rq[q];
+                if (jj == lo) dg_l = rq[q];
             }
             const double xn2 = wave_sum(xl);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // red2[16], red2[17] written by this wave
-            const double alpha = (lo + 1 < n) ? red2[16] : 0.0;
-            const double diag = red2[17];
+            const double alpha = (lo + 1 < n) ? lane_bcast(al_l, (lo + 1) & 63) : 0.0;      // the two entries sit in known lanes
+            const double diag = lane_bcast(dg_l, lo & 63);
             double scal = 0.0, betan = alpha;
             taun = 0.0;
             if (nk <= n - 3 && xn2 != 0.0) {
