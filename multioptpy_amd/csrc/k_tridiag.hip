@@ -566,7 +566,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
                     for (;;) {
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            const u64 *q = &PARTc[((size_t)(u0 + u) * n + j) * 2];
+                            const u64 *q = &PARTc[((size_t)(u0 + u < G ? u0 + u : 0) * n + j) * 2];      // (G = 4: the upper half repeats slot 0)
                             a[u] = ll_ld(q); c[u] = ll_ld(q + 1);
                         }
                         bool ok = true;
@@ -577,7 +577,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
                         __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) psum += ll_val(a[u], c[u]);
+                    for (int u = 0; u < 8; ++u) if (u0 + u < G) psum += ll_val(a[u], c[u]);
                 }
             }
             u64 a, c;
@@ -1269,7 +1269,7 @@ __device__ __forceinline__ double row16_sum(double v) {
 
 template <int NP16, int BK>
 __global__ void __launch_bounds__(256) k_tri_backtrans(int n, const double *__restrict__ A_, const double *__restrict__ TAU_,
-                                                       double *__restrict__ Zt_, int dbg) {
+                                                       double *__restrict__ Zt_, const int *__restrict__ bend_, int dbg) {
     constexpr int LEN = 16 * NP16;                          // padded reflector length
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *sv0 = sm, *sv1 = sm + (size_t)BK * LEN;         // two blocks of BK reflectors
@@ -1305,13 +1305,22 @@ __global__ void __launch_bounds__(256) k_tri_backtrans(int n, const double *__re
         for (int m = 0; m < NLD; ++m) { const int e = tid + 256 * m; if (e < BK * LEN) (buf ? sv1 : sv0)[e] = r[m]; }
         if (tid < BK) stau[buf * BK + tid] = tv;
     };
-    // reflector k acts on components k+1 .. n-1; applied in the order k = n-3 .. 0  (Q = H_0 H_1 ... H_{n-3})
+    // reflector k acts on components k+1 .. n-1; applied in the order k = n-3 .. 0  (Q = H_0 H_1 ... H_{n-3}).
+    // An eigenvector of the tridiagonal lives on its unreduced block [s, t) only, so reflectors with k + 1 >= t do not touch it:
+    // the sweep starts at k = (largest block end among the 16 vectors of this workgroup) - 2.  Split spectra (the usual case on
+    // this path) skip about half of the work; one full block skips nothing.
+    int kfirst = n - 3;
+    if (bend_) {
+        int tmax = 0;
+        for (int q = 0; q < 16; ++q) { const int jj = blockIdx.x * 16 + q; if (jj < n) { const int t = bend_[(size_t)b * n + jj]; tmax = t > tmax ? t : tmax; } }
+        kfirst = (tmax - 2 < n - 3) ? tmax - 2 : n - 3;
+    }
     double pre[NLD], ptau;
-    fetch(n - 3, pre, ptau);
+    fetch(kfirst, pre, ptau);
     stage(0, pre, ptau);
     __syncthreads();
     int buf = 0;
-    for (int kb = n - 3; kb >= 0; kb -= BK) {
+    for (int kb = kfirst; kb >= 0; kb -= BK) {
         fetch(kb - BK, pre, ptau);                             // in flight during the arithmetic below
         for (int c = 0; c < BK; ++c) {
             const int k = kb - c;
@@ -1414,17 +1423,18 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     const bool persist = multi && getenv("MOPT_TRI_PERSIST1") && !getenv("MOPT_TRI_NOPERSIST") && lds_for(G) <= (size_t)ctx->lds_limit - 4096 &&
                          G <= ctx->num_cu && n <= 1024 && 4 * G + 4 <= n;
     // row-per-wave variant (k_tri_persist2): 16 waves, accp[16][n]
-    int G2 = 8;
+    int G2 = getenv("MOPT_TRI_G") ? atoi(getenv("MOPT_TRI_G")) : 8;
     auto lds2_for = [&](int G_) { return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(5 + 16) * n) * 8; };
-    while (G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
+    const bool g_forced = getenv("MOPT_TRI_G") != nullptr;      // experiment: register-resident rows with a forced group size
+    while (!g_forced && G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
     // More workgroups per matrix when CUs are idle (few matrices per GPU) do not pay: measured at n = 300 with 4-16 matrices,
     // G = 8 / 16 / 32 -> poll 1.9 / 2.8 / 4.5 us per step against 1.9 / 1.5 / 1.3 us for LDS pass + barrier.  MOPT_TRI_GMAX
     // (default 8) raises the cap for experiments.
     {
         const int gmax = getenv("MOPT_TRI_GMAX") ? atoi(getenv("MOPT_TRI_GMAX")) : 8;
-        while (2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
+        while (!g_forced && 2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
     }
-    bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && lds2_for(G2) <= (size_t)ctx->lds_limit - 4096 &&
+    bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && (g_forced || lds2_for(G2) <= (size_t)ctx->lds_limit - 4096) &&
                     G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 4 <= n;
     if (persist2 && !getenv("MOPT_TRI_FORCEPERSIST")) {
         // Persistent kernel or one launch per Householder step?  Rough costs from the measurements in DESIGN.md section 5:
@@ -1447,7 +1457,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         // register-resident rows when the tile per lane is small enough: TR rows x CH chunks <= 16 doubles
         const int tr = (rows_for(G2) + 15) / 16;
         size_t lds_use = lds2_for(G2);
-        if (!getenv("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
+        if (getenv("MOPT_TRI_G") && ch == 5 && tr == 5) { fn = (const void *)k_tri_persist2<5, 5>; lds_use = (size_t)(5 + 16) * n * 8; }
+        else if (!getenv("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
             const int chs = ch <= 6 ? ch : 8;
 #define P3(C, T) ((const void *)k_tri_persist2<C, T>)
 #define P3T(C) (tr == 1 ? P3(C, 1) : tr == 2 ? P3(C, 2) : P3(C, 3))
@@ -1564,7 +1575,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         // BK reflectors per staged block, chosen so that the two blocks stay near 20 KB of LDS: with 39 KB (BK = 8 at n = 300) only
         // two workgroups fit a CU and the 608 workgroups of the headline band ran in two rounds (0.30 ms); BK = 4: one round, 0.24 ms
 #define BT(NP, BK) do { const size_t lds = ((size_t)2 * BK * 16 * NP + 2 * BK) * 8; \
-        hipLaunchKernelGGL((k_tri_backtrans<NP, BK>), g, dim3(256), lds, ctx->stream, n, d_A, d_TAU, d_Vt, bt_dbg); } while (0)
+        hipLaunchKernelGGL((k_tri_backtrans<NP, BK>), g, dim3(256), lds, ctx->stream, n, d_A, d_TAU, d_Vt, (const int *)d_bend, bt_dbg); } while (0)
         if (np16 <= 2) BT(2, 8); else if (np16 <= 4) BT(4, 8); else if (np16 <= 6) BT(6, 8); else if (np16 <= 8) BT(8, 8); else if (np16 <= 10) BT(10, 8);
         else if (np16 <= 12) BT(12, 6); else if (np16 <= 14) BT(14, 5); else if (np16 <= 16) BT(16, 5); else if (np16 <= 19) BT(19, 4); else if (np16 <= 24) BT(24, 3);
         else if (np16 <= 32) BT(32, 2); else if (np16 <= 40) BT(40, 2); else if (np16 <= 48) BT(48, 1); else if (np16 <= 64) BT(64, 1); else BT(96, 1);
