@@ -1030,23 +1030,35 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
     }
 }
 
-// After the bisection: publish the split off-diagonal and build the cluster table (dstein: a new cluster when
-// lambda_j - lambda_{j-1} > 1e-3 * ||T_block||_1).  One workgroup per matrix.  dynamic LDS: n ints
-__global__ void __launch_bounds__(256) k_tri_clusters(int n, const double *__restrict__ D_, double *__restrict__ E_, const double *__restrict__ WT_,
-                                                      const int *__restrict__ bstart_, const double *__restrict__ onenrm_,
-                                                      int *__restrict__ cstart_, int *__restrict__ ncl_) {
+// After the bisection: publish the split off-diagonal and build TWO cluster tables.  One workgroup per matrix.
+//   tight clusters (gap <= TRI_TIGHT ||T_block||_1): eigenvalues that inverse iteration cannot separate on its own; they are
+//       processed in sequence by one wave with perturbed shifts and re-orthogonalisation in every iteration (dstein);
+//   loose clusters (gap <= 1e-3 ||T_block||_1, dstein's criterion): their vectors are computed independently (one wave per
+//       tight cluster, all at once) and orthogonalised afterwards by k_tri_reorth.  With gaps above TRI_TIGHT the shifted
+//       solve suppresses the neighbours by > 1e8 per iteration, so the independent vectors are accurate to eps / gap and
+//       Gram-Schmidt only removes that residue.  dstein's strictly sequential treatment of a 1e-3 cluster made one wave walk
+//       >100 vectors of a molecular Hessian's dense low end (122 ms for one 300 x 300 matrix).
+// Tables: tight at cstart_[b n ..], ncl_[b]; loose at cstart_[(batch + b) n ..], ncl_[batch + b].   dynamic LDS: 2 n ints
+constexpr double TRI_TIGHT = 1e-7;
+__global__ void __launch_bounds__(256) k_tri_clusters(int n, int batch, const double *__restrict__ D_, double *__restrict__ E_,
+                                                      const double *__restrict__ WT_, const int *__restrict__ bstart_,
+                                                      const double *__restrict__ onenrm_, int *__restrict__ cstart_, int *__restrict__ ncl_) {
     extern __shared__ __attribute__((aligned(16))) int flg[];
+    int *flgL = flg + n;
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *D = D_ + (size_t)b * n, *WT = WT_ + (size_t)b * n, *onenrm = onenrm_ + (size_t)b * n;
     double *E = E_ + (size_t)b * n;
     const int *bstart = bstart_ + (size_t)b * n;
-    int *cstart = cstart_ + (size_t)b * n;
+    int *cstart = cstart_ + (size_t)b * n, *cstartL = cstart_ + (size_t)(batch + b) * n;
     for (int i = tid; i < n; i += blockDim.x) {
         if (i < n - 1) {
             const double ei = E[i];
             if (fabs(ei) <= 32.0 * DEPS * (fabs(D[i]) + fabs(D[i + 1])) || fabs(ei) < DTINY) E[i] = 0.0;
         } else E[i] = 0.0;
-        flg[i] = ((i == bstart[i]) || (fabs(WT[i] - WT[i - 1]) > 1e-3 * onenrm[i])) ? 1 : 0;
+        const bool first = (i == bstart[i]);
+        const double gap = first ? 0.0 : fabs(WT[i] - WT[i - 1]);
+        flg[i] = (first || gap > TRI_TIGHT * onenrm[i]) ? 1 : 0;
+        flgL[i] = (first || gap > 1e-3 * onenrm[i]) ? 1 : 0;
     }
     __syncthreads();
     if (tid == 0) {
@@ -1054,6 +1066,72 @@ __global__ void __launch_bounds__(256) k_tri_clusters(int n, const double *__res
         for (int j = 0; j < n; ++j) if (flg[j]) cstart[nc++] = j;
         ncl_[b] = nc;
     }
+    if (tid == 64) {
+        int nc = 0;
+        for (int j = 0; j < n; ++j) if (flgL[j]) cstartL[nc++] = j;
+        ncl_[batch + b] = nc;
+    }
+}
+
+// Orthogonalise the vectors of every loose cluster that spans more than one tight cluster.  The independently iterated
+// vectors overlap by eps / gap <= ~1e-8 only, so one symmetric (Loewdin) step  Z' = (3 I - G) Z / 2,  G = Z Z^T,  leaves
+// overlaps of order |G - I|^2 < 1e-15; it is applied twice.  No vector waits for another: workgroup j forms row j of G (its
+// vector against the whole cluster, one dot per wave at a time) and then its new vector, written to the scratch copy Z2;
+// k_tri_lowdin_copy moves the rows back.  grid (n, batch), one workgroup per eigenvector.   dynamic LDS: n doubles
+__device__ __forceinline__ bool loose_cluster_of(int n, int batch, int b, int j, const int *bstart_, const int *bend_, const int *cstart_,
+                                                 const int *ncl_, const double *WT, const double *onenrm, int small_max, int &j0, int &j1,
+                                                 int &s, int &t) {
+    const int *cstartL = cstart_ + (size_t)(batch + b) * n;
+    const int ncL = ncl_[batch + b];
+    s = bstart_[(size_t)b * n + j]; t = bend_[(size_t)b * n + j];
+    const int m = t - s;
+    if (m < 2 || m <= small_max) return false;
+    int lo = 0, hi = ncL - 1;                                   // last loose cluster start <= j
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cstartL[mid] <= j) lo = mid; else hi = mid - 1; }
+    j0 = cstartL[lo];
+    j1 = (lo + 1 < ncL && cstartL[lo + 1] < t) ? cstartL[lo + 1] : t;
+    if (j1 - j0 < 2) return false;
+    for (int i = j0 + 1; i < j1; ++i) if (fabs(WT[i] - WT[i - 1]) > TRI_TIGHT * onenrm[i]) return true;     // more than one tight cluster
+    return false;
+}
+
+__global__ void __launch_bounds__(1024) k_tri_lowdin(int n, int batch, const int *__restrict__ bstart_, const int *__restrict__ bend_,
+                                                    const int *__restrict__ cstart_, const int *__restrict__ ncl_, const double *__restrict__ WT_,
+                                                    const double *__restrict__ onenrm_, const double *__restrict__ Zt_, double *__restrict__ Z2_,
+                                                    int small_max) {
+    extern __shared__ __attribute__((aligned(16))) double grow[];
+    const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int j0, j1, s, t;
+    if (!loose_cluster_of(n, batch, b, j, bstart_, bend_, cstart_, ncl_, WT_ + (size_t)b * n, onenrm_ + (size_t)b * n, small_max, j0, j1, s, t)) return;
+    const int m = t - s;
+    const double *Z = Zt_ + (size_t)b * n * n + s;
+    const double *zj = Z + (size_t)j * n;
+    const int nwv = blockDim.x >> 6;
+    for (int i = j0 + wid; i < j1; i += nwv) {
+        const double *zi = Z + (size_t)i * n;
+        double d = 0.0;
+        for (int k = lane; k < m; k += WAVE) d += zi[k] * zj[k];
+        d = wave_sum(d);
+        if (lane == 0) grow[i - j0] = d;
+    }
+    __syncthreads();
+    double *out = Z2_ + (size_t)b * n * n + (size_t)j * n + s;
+    for (int k = tid; k < m; k += blockDim.x) {
+        double acc = 1.5 * zj[k];
+        for (int i = j0; i < j1; ++i) acc -= 0.5 * grow[i - j0] * Z[(size_t)i * n + k];
+        out[k] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_tri_lowdin_copy(int n, int batch, const int *__restrict__ bstart_, const int *__restrict__ bend_,
+                                                         const int *__restrict__ cstart_, const int *__restrict__ ncl_, const double *__restrict__ WT_,
+                                                         const double *__restrict__ onenrm_, double *__restrict__ Zt_, const double *__restrict__ Z2_,
+                                                         int small_max) {
+    const int b = blockIdx.y, j = blockIdx.x;
+    int j0, j1, s, t;
+    if (!loose_cluster_of(n, batch, b, j, bstart_, bend_, cstart_, ncl_, WT_ + (size_t)b * n, onenrm_ + (size_t)b * n, small_max, j0, j1, s, t)) return;
+    const size_t off = (size_t)b * n * n + (size_t)j * n + s;
+    for (int k = threadIdx.x; k < t - s; k += blockDim.x) Zt_[off + k] = Z2_[off + k];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1397,10 +1475,10 @@ __global__ void __launch_bounds__(256) k_tri_sort(int n, int npow2, const double
 static int g_tri_attr = 0, g_tri_attr2 = 0;
 
 // A is destroyed (reflectors are left in its rows).  Work arrays: d_D, d_E, d_TAU, d_WT, d_onenrm: batch*n doubles each;
-// d_bstart, d_bend, d_cstart: batch*n ints; d_ncl, d_fail: batch ints.
+// d_Z2: batch*n*n doubles (scratch copy of the eigenvectors for the cluster orthogonalisation).  d_bstart, d_bend: batch*n ints; d_cstart: 2*batch*n ints (tight and loose cluster tables); d_ncl: 2*batch ints; d_fail: batch ints.
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info) {
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2) {
     using namespace mopt;
     if (n < 3) { ctx->err = "tridiagonal eigen-solver needs n >= 3"; return MOPT_E_ARG; }
     if (!g_tri_attr) {
@@ -1556,7 +1634,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                            ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm, small_max);
         if (small_max > 0)
             hipLaunchKernelGGL(k_tri_small, dim3(n, batch), dim3(64), 0, ctx->stream, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
-        hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)n * 4, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl);
+        hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)2 * n * 4, ctx->stream, n, batch, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl);
     }
     {
         mopt_scope sc(ctx, "eigh_invit", 1);
@@ -1566,6 +1644,12 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const int extra = getenv("MOPT_INVIT_EXTRA") ? atoi(getenv("MOPT_INVIT_EXTRA")) : 1;
         hipLaunchKernelGGL(k_tri_invit, dim3(n, batch), dim3(64), perwave, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_cstart,
                            d_ncl, d_onenrm, d_Vt, d_fail, extra, getenv("MOPT_INVIT_DBG") ? 1 : 0, small_max);
+        for (int pass = 0; pass < 2; ++pass) {
+            hipLaunchKernelGGL(k_tri_lowdin, dim3(n, batch), dim3(n > 256 ? 1024 : 256), (size_t)n * 8, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT,
+                               d_onenrm, d_Vt, d_Z2, small_max);
+            hipLaunchKernelGGL(k_tri_lowdin_copy, dim3(n, batch), dim3(256), 0, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT, d_onenrm,
+                               d_Vt, d_Z2, small_max);
+        }
     }
     {
         mopt_scope sc(ctx, "eigh_backtrans", 1);

@@ -162,11 +162,11 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     if (mopt_eigh_algo(n) == 1) {
         DBuf dsc, dsi;
         const size_t nvi = (size_t)batch * n;
-        TRY(dsc.alloc(ctx, 5 * nvi * 8)); TRY(dsi.alloc(ctx, (3 * nvi + 2 * batch) * 4));
+        TRY(dsc.alloc(ctx, 5 * nvi * 8)); TRY(dsi.alloc(ctx, (4 * nvi + 3 * batch) * 4));
         double *sc = dsc.as<double>();
         int *si = dsi.as<int>();
         TRY(mopt_launch_eigh_tridiag(ctx, n, batch, dA.as<double>(), dVt.as<double>(), sc, sc + nvi, sc + 2 * nvi, sc + 3 * nvi, sc + 4 * nvi,
-                                     si, si + nvi, si + 2 * nvi, si + 3 * nvi, si + 3 * nvi + batch, dW.as<double>(), dperm.as<int>(), dinfo.as<int>()));
+                                     si, si + nvi, si + 2 * nvi, si + 4 * nvi, si + 4 * nvi + 2 * batch, dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), dG.as<double>()));
         MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     } else
     TRY(mopt_launch_eigh(ctx, n, batch, dA.as<double>(), dsig.as<double>(), dG.as<double>(), dVt.as<double>(), drot.as<int>(),

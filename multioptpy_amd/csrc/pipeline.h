@@ -11,7 +11,7 @@ constexpr int JAC_MAX_SWEEPS = 30;
 }
 
 // scratch of the reduction-route eigen-solver (k_tridiag.hip)
-struct TriScratch { double *D, *E, *TAU, *WT, *onenrm; int *bstart, *bend, *cstart, *ncl, *fail; };
+struct TriScratch { double *D, *E, *TAU, *WT, *onenrm, *Z2; int *bstart, *bend, *cstart, *ncl, *fail; };
 
 // Device workspace of one batched RSIRFO.run (all pointers are device pointers).
 struct RsirfoWork {
@@ -57,7 +57,7 @@ int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double 
 int mopt_launch_dgemm(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_B, const double *d_addscale, double *d_C);
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info);
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2);
 // algorithm switch: 0 = block Jacobi (k_eigh.hip), 1 = tridiagonal reduction route (k_tridiag.hip); env MOPT_EIGH_ALGO overrides
 int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm);
 int mopt_eigh_algo(int n);   // 1 = reduction route (k_tridiag.hip), 0 = one-sided Jacobi (k_eigh.hip)

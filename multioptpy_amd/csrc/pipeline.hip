@@ -18,7 +18,8 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
     tot += al(nv * 4);                 // perm
     tot += 3 * al((size_t)batch * 8) + al((size_t)batch * 8 * 8);
     tot += al((size_t)batch * 2 * 4) + al((size_t)batch * (mopt::JAC_MAX_SWEEPS + 1) * 4) + 2 * al((size_t)batch * 4);
-    tot += 5 * al(nv * 8) + 3 * al(nv * 4) + 2 * al((size_t)batch * 4);      // reduction-route eigen-solver scratch
+    tot += 5 * al(nv * 8) + 2 * al(nv * 4) + al(2 * nv * 4) + al((size_t)2 * batch * 4) + al((size_t)batch * 4);      // reduction-route eigen-solver scratch
+    tot += al((size_t)batch * n * n * 8);                                                                                // ... and its second eigenvector buffer
     tot += al(batch * sizeof(mopt::UpdateCoef)) + al(batch * sizeof(mopt_rsirfo_params)) + al(batch * sizeof(mopt_rsirfo_state));
     if (hipMalloc(&block, tot) != hipSuccess) { c->err = "hipMalloc failed (RSIRFO workspace)"; block = nullptr; return MOPT_E_NOMEM; }
     char *p = (char *)block;
@@ -42,8 +43,9 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
     states = (mopt_rsirfo_state *)take(batch * sizeof(mopt_rsirfo_state));
     tri.D = (double *)take(nv * 8); tri.E = (double *)take(nv * 8); tri.TAU = (double *)take(nv * 8); tri.WT = (double *)take(nv * 8);
     tri.onenrm = (double *)take(nv * 8);
-    tri.bstart = (int *)take(nv * 4); tri.bend = (int *)take(nv * 4); tri.cstart = (int *)take(nv * 4);
-    tri.ncl = (int *)take((size_t)batch * 4); tri.fail = (int *)take((size_t)batch * 4);
+    tri.bstart = (int *)take(nv * 4); tri.bend = (int *)take(nv * 4); tri.cstart = (int *)take(2 * nv * 4);     // tight + loose cluster tables
+    tri.ncl = (int *)take((size_t)2 * batch * 4); tri.fail = (int *)take((size_t)batch * 4);
+    tri.Z2 = (double *)take((size_t)batch * n * n * 8);
     return MOPT_OK;
 }
 
@@ -74,7 +76,7 @@ int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm) {
         // reduction route: work on a copy (the reflectors overwrite it), eigenvectors land in Vt
         MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.Gt, wk.A, (size_t)batch * n * n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
         return mopt_launch_eigh_tridiag(ctx, n, batch, wk.Gt, wk.Vt, wk.tri.D, wk.tri.E, wk.tri.TAU, wk.tri.WT, wk.tri.onenrm, wk.tri.bstart,
-                                        wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo);
+                                        wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo, wk.tri.Z2);
     }
     return mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm);
 }
