@@ -593,3 +593,25 @@ def test_band_tiny_shapes_vs_oracle(shape):
         newX, _ = band.download(want_force=True)
         assert np.abs(newX - ref).max() < 1e-8, (shape, it, np.abs(newX - ref).max())
     band.close()
+
+
+def test_band_long_run_vs_oracle():
+    """Twelve consecutive band steps (I = 8, N = 14, exact LJ Hessians to start with: dense spectra with clusters, then
+    quasi-Newton updates) against the oracle: no drift, no solver failure, trust radii identical."""
+    from multioptpy_amd.band import Band
+    I, N = 8, 14
+    X0 = cases.band(I, N)
+    hess = [cases.lj(X0[i], hessian=True)[2] for i in range(I)]
+    band = Band(I, N)
+    for i in range(I):
+        band.set_hessian(i, hess[i])
+    worst = 0.0
+    for it, (X, E, Gr, ref) in enumerate(_oracle_band_steps(X0, 12, hessians=[h.copy() for h in hess])):
+        band.upload(X, E, Gr)
+        band.step(it)
+        newX, _ = band.download(want_force=True)
+        err = np.abs(newX - ref).max()
+        worst = max(worst, err)
+        assert err < 1e-8, (it, err)
+    band.close()
+    print("12 steps: worst deviation", worst)
