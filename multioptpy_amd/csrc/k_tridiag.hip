@@ -1,12 +1,20 @@
 // Batched symmetric eigen-solver, reduction route (LAPACK dsytrd / dstebz / dstein / dormtr restated for gfx950):
-//   k_tridiag        Householder tridiagonalisation A = Q T Q^T, one workgroup per matrix, the trailing matrix streamed from
-//                    L2 (n = 300: 720 KB), reflectors kept in the rows of A
-//   k_tri_bisect     splitting at negligible off-diagonals, Sturm-count bisection, one thread per eigenvalue; cluster table
-//   k_tri_invit      inverse iteration per eigenvalue (dlagtf / dlagts pivoted tridiagonal LU), one wave per cluster with
-//                    modified Gram-Schmidt inside a cluster (eigenvalues closer than 1e-3 ||T||)
-//   k_tri_backtrans  V = Q Z: the n-2 reflectors applied to 16 eigenvectors per workgroup, reflector staged through LDS
+//   tridiagonalisation A = Q T Q^T, reflectors kept in the rows of A -- three forms, chosen by mopt_launch_eigh_tridiag:
+//     k_tri_persist2<CH,TR>  ONE launch for all n-1 Householder steps, 8 workgroups per matrix, rows on chip (registers
+//                            when TR > 0, LDS otherwise), tagged-word hand-off between the workgroups (the default)
+//     k_tri_step             one launch per Householder step, 8 workgroups per matrix (large n, large batches)
+//     k_tridiag              one workgroup per matrix (n < 32);   k_tri_persist: the first persistent form (MOPT_TRI_PERSIST1)
+//   k_tri_bisect     splitting at negligible off-diagonals, nine-section Sturm search, 8 lanes per eigenvalue
+//   k_tri_small      unreduced blocks of 2..32 rows solved whole by a wave-level one-sided Jacobi
+//   k_tri_clusters   tight (1e-7) and loose (1e-3) cluster tables
+//   k_tri_invit      inverse iteration (dlagtf / dlagts pivoted tridiagonal LU), one wave per tight cluster
+//   k_tri_lowdin     symmetric orthogonalisation of the loose clusters (independently iterated vectors)
+//   k_tri_backtrans  V = Q Z: 16 lanes per eigenvector, reflectors staged through LDS in blocks
+//   k_tri_sort       ascending order + status
 // ~ (4/3 + 2) n^3 flops instead of the ~70 n^3 of the Jacobi route (k_eigh.hip); same output contract:
-// W ascending, perm, Vt vector-major, einfo.
+// W ascending, perm, Vt vector-major, einfo.  Developer switches (environment): MOPT_TRI_PROF, MOPT_TRI_NOPERSIST,
+// MOPT_TRI_FORCEPERSIST, MOPT_TRI_PERSIST1, MOPT_TRI_NOREG, MOPT_TRI_G, MOPT_TRI_GMAX, MOPT_TRI_SMALL, MOPT_INVIT_EXTRA,
+// MOPT_INVIT_DBG, MOPT_BT_DBG, MOPT_TRI_INJECT_FAIL.
 #include <cstdlib>
 #include <cstdio>
 #include <vector>
