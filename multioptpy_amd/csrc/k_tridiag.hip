@@ -270,6 +270,22 @@ __device__ __forceinline__ void ll_put(u64 *p, double v, unsigned tag) {
     __hip_atomic_store(p + 1, (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ u64 ll_ld(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Same words with XCD-local reach: workgroup-scope atomics compile to sc0 accesses (L1 bypassed, served by the XCD's L2), one
+// L2 round trip instead of two trips to the memory side.  Only valid between workgroups that share an XCD: k_tri_persist2
+// verifies that at run time (HW_REG_XCC_ID of all partners) and keeps the agent-scope form otherwise.
+__device__ __forceinline__ void ll_put_s(u64 *p, double v, unsigned tag, bool local) {
+    const u64 bits = (u64)__double_as_longlong(v), t = (u64)tag << 32;
+    if (local) {
+        __hip_atomic_store(p, (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(p + 1, (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else {
+        __hip_atomic_store(p, (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p + 1, (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ u64 ll_ld_s(const u64 *p, bool local) {
+    return local ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ double ll_val(u64 a, u64 c) { return __longlong_as_double((long long)((a & 0xffffffffull) | (c << 32))); }
 constexpr unsigned LL_SPIN_LIMIT = 2000000u;
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for the fabric
@@ -505,7 +521,8 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
 template <int CH, int TR>
 __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_cap, double *__restrict__ A_, double *__restrict__ D_,
                                                        double *__restrict__ E_, double *__restrict__ TAU_, u64 *__restrict__ XCH_,
-                                                       size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof) {
+                                                       size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof, int nmat,
+                                                       int per_x, int try_local) {
     constexpr int NW = 16;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[64];
@@ -516,7 +533,12 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     double *accp = sm + 3 * n;                              // [NW][n] partial SYMV per wave
     double *sps = sm + (size_t)(3 + NW) * n, *srow = sps + n;     // collected partial sums and pivot-row entries per column
     double *Aloc = sm + (size_t)(5 + NW) * n;               // [rows_cap][ns] rows owned by this workgroup
-    const int b = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    // Workgroup -> (matrix, member) so that the G members of a matrix get linear ids that are congruent mod 8: the dispatcher
+    // deals consecutive workgroups round-robin to the 8 XCDs, so the members land on ONE XCD and can exchange through its L2.
+    // (A wrong guess costs speed only: the placement is checked below.)   1-D grid of 8 * per_x * G workgroups.
+    const int lin = blockIdx.x, xcd_slot = lin >> 3;
+    const int b = (lin & 7) * per_x + xcd_slot / G, g = xcd_slot % G, tid = threadIdx.x;
+    if (b >= nmat || xcd_slot / G >= per_x) return;
     const int j = tid, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nw0 = (n + 63) >> 6;                           // waves that carry columns in the prologue
     const int chn = nw0, ns = 64 * chn;                      // column chunks in use, padded row stride of Aloc
@@ -528,6 +550,35 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     for (int i = tid; i < 3 * n; i += blockDim.x) sm[i] = 0.0;   // v, w, v': the branch-free main pass multiplies them by zero at k = -1
     int r_end = 0;                                           // local rows that exist (global index < n)
     for (int r = 0; r < rows_cap; ++r) r_end += ((g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC) < n) ? 1 : 0;
+    // ---- do all members of this matrix sit on one XCD?  Every member publishes its XCC id (agent scope, tagged) and reads all G.
+    __shared__ int s_xloc;
+    {
+        u64 *XID = ROWX + (size_t)4 * n;                     // [G] words behind the row buffers
+        if (tid == 0) {
+            const unsigned myx = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF;      // HW_REG_XCC_ID[3:0]
+            __hip_atomic_store(&XID[g], ((u64)0x5EEDu << 32) | myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int same = try_local ? 1 : 0;
+            for (int u = 0; u < G; ++u) {
+                u64 w = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    w = __hip_atomic_load(&XID[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(w >> 32) == 0x5EEDu) break;
+                    if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if ((unsigned)(w & 0xF) != myx) same = 0;
+            }
+            s_xloc = same;
+            if (prof && b < 2) printf("[xcd] matrix %d member %d (workgroup %d): XCC %u, all members on one XCD: %d\n", b, g, lin, myx, same);
+        }
+        __syncthreads();
+    }
+    // Measured (tools/ubench/handoff.hip): a word stored with sc0 is seen by an sc1 load of a workgroup on the SAME XCD after
+    // 0.32 us (sc1/sc1: 0.49 us, same or different XCD); sc0 loads never see it (they may hit this CU's L1 for ever, even
+    // after buffer_inv sc0).  So only the stores take the XCD-local form, and only when the placement check above passed.
+    const bool xloc = false;                                 // loads: always agent scope
+    const bool xlocs = (s_xloc != 0);                        // stores: XCD-local when every member sits on one XCD
     constexpr int TRR = TR > 0 ? TR : 1;
     double areg[TRR][CH];                                    // (TR > 0) the rows of this wave
     if constexpr (TR > 0) {
@@ -541,7 +592,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
         __syncthreads();
         if (g == 0 && wid == 0) {                            // row 0 (local row 0 of workgroup 0): tag 1 in buffer 1 (step k = -1)
 #pragma unroll
-            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) ll_put(&ROWX[((size_t)1 * n + jj) * 2], areg[0][q], 1u); }
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) ll_put_s(&ROWX[((size_t)1 * n + jj) * 2], areg[0][q], 1u, xlocs); }
         }
     } else {
         for (int r = wid; r < r_end; r += NW) {
@@ -550,7 +601,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
             for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) Aloc[r * ns + jj] = (jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
         }
         __syncthreads();
-        if (g == 0 && j < n) ll_put(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u);     // row 0: tag 1 in buffer 1 (step k = -1)
+        if (g == 0 && j < n) ll_put_s(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u, xlocs);     // row 0: tag 1 in buffer 1 (step k = -1)
     }
     double tau = 0.0, taun = 0.0;
     double *sv = sva, *svn = svb;
@@ -564,6 +615,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
         u64 *ROWn = ROWX + (size_t)nxt * n * 2;
         const bool mine = (j >= lo && j < n);
         // ---- collect: the G partial SYMV vectors of step k and row lo, column j
+        // (a one-word "ready" flag per member in front of the full tagged read was tried and lost: 1.32 ms against 1.25 ms)
         double psum = 0.0, rowj = 0.0;
         if (prof) t0 = wall_clock64();
         if (mine) {
@@ -575,7 +627,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
                             const u64 *q = &PARTc[((size_t)(u0 + u < G ? u0 + u : 0) * n + j) * 2];      // (G = 4: the upper half repeats slot 0)
-                            a[u] = ll_ld(q); c[u] = ll_ld(q + 1);
+                            a[u] = ll_ld_s(q, xloc); c[u] = ll_ld_s(q + 1, xloc);
                         }
                         bool ok = true;
 #pragma unroll
@@ -592,7 +644,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
             unsigned spins = 0;
             for (;;) {
                 const u64 *q = &ROWc[(size_t)j * 2];
-                a = ll_ld(q); c = ll_ld(q + 1);
+                a = ll_ld_s(q, xloc); c = ll_ld_s(q + 1, xloc);
                 if ((unsigned)(a >> 32) == tag && (unsigned)(c >> 32) == tag) break;
                 if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
@@ -781,7 +833,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
                         }
                         if (gi == lo + 1) {                                             // the next pivot row: publish it
 #pragma unroll
-                            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put(&ROWn[(size_t)jj * 2], areg[t][q], tag + 1u); }
+                            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put_s(&ROWn[(size_t)jj * 2], areg[t][q], tag + 1u, xlocs); }
                         }
                     }
                 }
@@ -811,7 +863,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
             if (own_next && r_first < r_end && wid == 0) {
                 const double *Ar = Aloc + r_first * ns;
 #pragma unroll
-                for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put(&ROWn[(size_t)jj * 2], Ar[jj], tag + 1u); }
+                for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put_s(&ROWn[(size_t)jj * 2], Ar[jj], tag + 1u, xlocs); }
             }
         }
             }
@@ -821,7 +873,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
         if (j > lo && j < n) {
             double a = 0.0;
             for (int w = 0; w < nact; ++w) a += accp[w * n + j];
-            ll_put(&PARTn[((size_t)g * n + j) * 2], a, tag + 1u);
+            ll_put_s(&PARTn[((size_t)g * n + j) * 2], a, tag + 1u, xlocs);
         }
         tau = taun;
         { double *t = sv; sv = svn; svn = t; }
@@ -1521,7 +1573,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         while (!g_forced && 2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
     }
     bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && (g_forced || lds2_for(G2) <= (size_t)ctx->lds_limit - 4096) &&
-                    G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 4 <= n;
+                    G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 5 <= n;
     if (persist2 && !getenv("MOPT_TRI_FORCEPERSIST")) {
         // Persistent kernel or one launch per Householder step?  Rough costs from the measurements in DESIGN.md section 5:
         // persistent: (4 + G/4) us per step and per group of num_cu/G matrices (6.2 us at G = 8; the exchange grows with G);
@@ -1567,18 +1619,21 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         long long *d_prof = nullptr;
         if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
-        const size_t xwords = ((size_t)4 * G + 4) * n;
+        const size_t xwords = ((size_t)4 * G + 4) * n + G;     // partial vectors, pivot rows, XCC ids
         MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
+        int try_local = getenv("MOPT_TRI_NOLOCAL") ? 0 : 1;   // XCD-local (sc0) stores when the run-time placement check allows
         for (int b0 = 0; b0 < batch; b0 += per) {
             const int nb_ = (batch - b0 < per) ? batch - b0 : per;
+            int per_x = (nb_ + 7) / 8;                          // matrices per XCD
+            int nmat = nb_;
             int n_ = n, G_ = G;
             double *pA = d_A + (size_t)b0 * n * n, *pD = d_D + (size_t)b0 * n, *pE = d_E + (size_t)b0 * n, *pT = d_TAU + (size_t)b0 * n;
             u64 *pX = (u64 *)(d_Vt + (size_t)b0 * n * n);
             size_t stride = (size_t)n * n;
             int *pF = d_fail + b0;
             long long *pP = d_prof ? d_prof + (size_t)b0 * G * 8 : nullptr;
-            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP};
-            MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(G, nb_), dim3(1024), args, lds_use, ctx->stream));
+            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP, &nmat, &per_x, &try_local};
+            MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(8 * per_x * G), dim3(1024), args, lds_use, ctx->stream));
         }
         if (d_prof) {
             std::vector<long long> h((size_t)batch * G * 8);
