@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(1024) k_tri_step(int n, int k, double *__restr
 // partner's tag t+1, which partners only produce after they have finished reading tag t -- so nothing is overwritten early.
 // Requires G * nbatch <= #CUs (one workgroup per CU by LDS size) so that all participants are resident; every poll is bounded.
 typedef unsigned long long u64;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ll_put(u64 *p, double v, unsigned tag) {
     const u64 bits = (u64)__double_as_longlong(v), t = (u64)tag << 32;
     __hip_atomic_store(p, (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -282,6 +283,15 @@ __device__ __forceinline__ void ll_put_s(u64 *p, double v, unsigned tag, bool lo
         __hip_atomic_store(p, (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(p + 1, (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+// both tagged words of a value in ONE 16-byte store (aux 1 = sc0: XCD-local, aux 16 = sc1: write-through); every 8-byte half is
+// still self-validating, a reader that sees only one of them reads again
+__device__ __forceinline__ void put16(__amdgpu_buffer_rsrc_t rs, int byte_off, double v, unsigned tag, bool local) {
+    const u64 bits = (u64)__double_as_longlong(v);
+    u32x4 w;
+    w[0] = (unsigned)bits; w[1] = tag; w[2] = (unsigned)(bits >> 32); w[3] = tag;
+    if (local) __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 1);
+    else __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 16);
 }
 __device__ __forceinline__ u64 ll_ld_s(const u64 *p, bool local) {
     return local ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -579,6 +589,8 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     // after buffer_inv sc0).  So only the stores take the XCD-local form, and only when the placement check above passed.
     const bool xloc = false;                                 // loads: always agent scope
     const bool xlocs = (s_xloc != 0);                        // stores: XCD-local when every member sits on one XCD
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(PARTX, 0, (int)((size_t)2 * G * n * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(ROWX, 0, (int)((size_t)2 * n * 16), 0x00020000);
     constexpr int TRR = TR > 0 ? TR : 1;
     double areg[TRR][CH];                                    // (TR > 0) the rows of this wave
     if constexpr (TR > 0) {
@@ -592,7 +604,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
         __syncthreads();
         if (g == 0 && wid == 0) {                            // row 0 (local row 0 of workgroup 0): tag 1 in buffer 1 (step k = -1)
 #pragma unroll
-            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) ll_put_s(&ROWX[((size_t)1 * n + jj) * 2], areg[0][q], 1u, xlocs); }
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16(rsR, (int)((((size_t)1 * n) + jj) * 16), areg[0][q], 1u, xlocs); }
         }
     } else {
         for (int r = wid; r < r_end; r += NW) {
@@ -601,7 +613,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
             for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) Aloc[r * ns + jj] = (jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
         }
         __syncthreads();
-        if (g == 0 && j < n) ll_put_s(&ROWX[((size_t)1 * n + j) * 2], Aloc[j], 1u, xlocs);     // row 0: tag 1 in buffer 1 (step k = -1)
+        if (g == 0 && j < n) put16(rsR, (int)((((size_t)1 * n) + j) * 16), Aloc[j], 1u, xlocs);     // row 0: tag 1 in buffer 1 (step k = -1)
     }
     double tau = 0.0, taun = 0.0;
     double *sv = sva, *svn = svb;
@@ -619,39 +631,43 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
         double psum = 0.0, rowj = 0.0;
         if (prof) t0 = wall_clock64();
         if (mine) {
+            // one 16-byte load fetches both tagged words of a value (each half is still validated on its own tag): half the
+            // L2 requests of two 8-byte loads -- the XCD's L2 request rate, not its latency, paces 32 polling workgroups
             if (k >= 0) {
-                for (int u0 = 0; u0 < G; u0 += 8) {              // G is a multiple of 8: sixteen loads in flight
-                    u64 a[8], c[8];
+                for (int u0 = 0; u0 < G; u0 += 8) {              // eight loads in flight
+                    u32x4 x[8];
                     unsigned spins = 0;
                     for (;;) {
+                        asm volatile("" ::: "memory");           // the buffer loads are ordinary loads to the compiler: re-issue them every pass
 #pragma unroll
                         for (int u = 0; u < 8; ++u) {
-                            const u64 *q = &PARTc[((size_t)(u0 + u < G ? u0 + u : 0) * n + j) * 2];      // (G = 4: the upper half repeats slot 0)
-                            a[u] = ll_ld_s(q, xloc); c[u] = ll_ld_s(q + 1, xloc);
+                            const int uu = (u0 + u < G) ? u0 + u : 0;        // (G = 4: the upper half repeats slot 0)
+                            x[u] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (int)((((size_t)cur * G + uu) * n + j) * 16), 0, 16);   // aux 16 = sc1
                         }
                         bool ok = true;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) ok = ok && ((unsigned)(a[u] >> 32) == tag) && ((unsigned)(c[u] >> 32) == tag);
+                        for (int u = 0; u < 8; ++u) ok = ok && (x[u][1] == tag) && (x[u][3] == tag);
                         if (ok) break;
                         if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) if (u0 + u < G) psum += ll_val(a[u], c[u]);
+                    for (int u = 0; u < 8; ++u)
+                        if (u0 + u < G) psum += __longlong_as_double((long long)((u64)x[u][0] | ((u64)x[u][2] << 32)));
                 }
             }
-            u64 a, c;
+            u32x4 xr;
             unsigned spins = 0;
             for (;;) {
-                const u64 *q = &ROWc[(size_t)j * 2];
-                a = ll_ld_s(q, xloc); c = ll_ld_s(q + 1, xloc);
-                if ((unsigned)(a >> 32) == tag && (unsigned)(c >> 32) == tag) break;
+                asm volatile("" ::: "memory");
+                xr = __builtin_amdgcn_raw_buffer_load_b128(rsR, (int)(((size_t)cur * n + j) * 16), 0, 16);
+                if (xr[1] == tag && xr[3] == tag) break;
                 if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            rowj = ll_val(a, c);
+            rowj = __longlong_as_double((long long)((u64)xr[0] | ((u64)xr[2] << 32)));
         }
-        if (prof) { lds_barrier(); t1 = wall_clock64(); t_poll += t1 - t0; t0 = t1; }
+        if (prof) { t1 = wall_clock64(); t_poll += t1 - t0; t0 = t1; }      // (recorded by the thread of the last column, see below)
         // ---- w_k = p + c v  (p = tau A v, c = -tau/2 p.v); the failure flag of the polls is read behind the same barrier.
         // Only the nw0 column waves do the arithmetic; the other waves just meet them at the barriers (they would otherwise
         // share the SIMDs' issue slots with the critical path).
@@ -833,7 +849,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
                         }
                         if (gi == lo + 1) {                                             // the next pivot row: publish it
 #pragma unroll
-                            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put_s(&ROWn[(size_t)jj * 2], areg[t][q], tag + 1u, xlocs); }
+                            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) put16(rsR, (int)((((size_t)nxt * n) + jj) * 16), areg[t][q], tag + 1u, xlocs); }
                         }
                     }
                 }
@@ -863,7 +879,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
             if (own_next && r_first < r_end && wid == 0) {
                 const double *Ar = Aloc + r_first * ns;
 #pragma unroll
-                for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) ll_put_s(&ROWn[(size_t)jj * 2], Ar[jj], tag + 1u, xlocs); }
+                for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) put16(rsR, (int)((((size_t)nxt * n) + jj) * 16), Ar[jj], tag + 1u, xlocs); }
             }
         }
             }
@@ -873,13 +889,13 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
         if (j > lo && j < n) {
             double a = 0.0;
             for (int w = 0; w < nact; ++w) a += accp[w * n + j];
-            ll_put_s(&PARTn[((size_t)g * n + j) * 2], a, tag + 1u, xlocs);
+            put16(rsP, (int)((((size_t)nxt * G + g) * n + j) * 16), a, tag + 1u, xlocs);
         }
         tau = taun;
         { double *t = sv; sv = svn; svn = t; }
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
     }
-    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
+    if (prof && tid == n - 1) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
     __syncthreads();
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
     {
