@@ -187,7 +187,7 @@ def main():
         # triangle (4 n^2); the back-transformation reads reflectors + eigenvectors and writes eigenvectors (20 n^2).
         share = {"eigh_jacobi": 16.0, "eigh_tridiag": 12.0, "eigh_backtrans": 20.0, "eigh_invit": 8.0, "hess_update": 24.0,
                  "project": 16.0, "rfo": 24.0}.get(dom, 80.0)
-        kname = {"eigh_jacobi": "k_jac_step", "eigh_tridiag": "k_tri_persist2", "eigh_backtrans": "k_tri_backtrans",
+        kname = {"eigh_jacobi": "k_jac_step", "eigh_tridiag": "k_tri_persist3", "eigh_backtrans": "k_tri_backtrans",
                  "eigh_invit": "k_tri_invit", "eigh_bisect": "k_tri_bisect"}.get(dom, dom)
         bytes_dom = share * n * n * count
         t_dom = fam[dom]["ms_per_step"] * 1e-3

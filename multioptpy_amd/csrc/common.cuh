@@ -24,16 +24,27 @@ __device__ __forceinline__ double dpp_f64(double old, double v) {
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
-// Sum over the 64 lanes, returned to every lane.  Order: pairs, quads, half rows, rows (16 lanes), then rows 0+1, 2+3, all.
-__device__ __forceinline__ double wave_sum(double v) {
-    v += dpp_f64<0xB1, 0xF>(0.0, v);       // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E, 0xF>(0.0, v);       // quad_perm [2,3,0,1]
-    v += dpp_f64<0x141, 0xF>(0.0, v);      // row_half_mirror
-    v += dpp_f64<0x140, 0xF>(0.0, v);      // row_mirror
-    v += dpp_f64<0x142, 0xA>(0.0, v);      // row_bcast15 into rows 1 and 3
-    v += dpp_f64<0x143, 0xC>(0.0, v);      // row_bcast31 into rows 2 and 3
-    return lane_bcast(v, 63);
+// The same move with bound_ctrl and all rows/banks enabled: no `old` operand to materialise (two v_mov_b32_dpp, nothing else);
+// a lane without a source lane (row_bcast into row 0) reads 0.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64z(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
+// Sum over the 64 lanes, valid in LANE 63 ONLY (other lanes hold partial sums).  Order: pairs, quads, half rows, rows (16
+// lanes), then row r += row r-1, then rows 2,3 += lane 31: lane 63 ends with ((r0+r1) + (r2+r3)) in the order r3 + r2, + (r1 + r0).
+__device__ __forceinline__ double wave_sum63(double v) {
+    v += dpp_f64z<0xB1>(v);                // quad_perm [1,0,3,2]
+    v += dpp_f64z<0x4E>(v);                // quad_perm [2,3,0,1]
+    v += dpp_f64z<0x141>(v);               // row_half_mirror
+    v += dpp_f64z<0x140>(v);               // row_mirror
+    v += dpp_f64z<0x142>(v);               // row_bcast15: lane 15 of row r to row r+1 (row 0 reads 0)
+    v += dpp_f64z<0x143>(v);               // row_bcast31: lane 31 to rows 2 and 3 (rows 0, 1 read 0)
+    return v;
+}
+// Sum over the 64 lanes, returned to every lane.
+__device__ __forceinline__ double wave_sum(double v) { return lane_bcast(wave_sum63(v), 63); }
 __device__ __forceinline__ double wave_max(double v) {
     v = fmax(v, dpp_f64<0xB1, 0xF>(v, v));
     v = fmax(v, dpp_f64<0x4E, 0xF>(v, v));

@@ -916,6 +916,297 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     }
 }
 
+// k_tri_persist3: row-dot form of the persistent reduction.  The symmetric matrix-vector product of step k is taken ROW-wise:
+// the wave that owns row i (all n columns of it, both triangles are kept current) updates the row with (v, w), multiplies it
+// with the next reflector and reduces over its lanes (DPP), so p_i = (A v')_i is complete inside one wave and goes straight
+// to the exchange.  Against k_tri_persist2 (column-wise partial sums per wave, summed over 16 waves and G workgroups):
+//   * no accp[16][n] partials, no barrier + 16-term sum behind the main pass,
+//   * the exchange carries n values per step instead of G n, every member reads 2 n tagged values instead of (G + 1) n,
+//   * wave 0 alone polls (CH + CH 16-byte loads per lane) and forms w and the next reflector in registers, the other 15
+//     waves meet it at the ONE workgroup barrier of the step; v is triple-, w double-buffered in LDS so that wave 0 may
+//     run one step ahead of a wave that has no live row (and hence no store that would order it).
+// The step is written as straight-line code: v, w and v' are kept in LDS over all 64 CH column slots with EXACT zeros in the
+// dead (j < lo) and pad (j >= n) slots, so dead columns, dead rows, a skipped update (tau = 0 gives w = 0) and the first step
+// (v = w = 0) need no predicate -- they ride along with zero weights.  Column lo of the live rows and row lo itself pick up
+// finite garbage (w_lo, v_lo = 1 are not zero); neither is read again (v'_lo = 0, and only columns > lo of a row are published).
+// Exchange words per matrix: P [2][n][2], ROW [2][n][2], XID [G].
+template <int CH, int TR>
+__global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_cap, double *__restrict__ A_, double *__restrict__ D_,
+                                                       double *__restrict__ E_, double *__restrict__ TAU_, u64 *__restrict__ XCH_,
+                                                       size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof, int nmat,
+                                                       int per_x, int try_local) {
+    constexpr int NW = 16, NS = 64 * CH;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_fail, s_xloc;
+    long long t_poll = 0, t_pro = 0, t_main = 0, t_bar = 0, t0 = 0, t1 = 0;
+    const long long c_start = prof ? clock64() : 0, w_start = prof ? wall_clock64() : 0;
+    double *vb = sm, *wb = sm + 3 * NS;                     // v[3][NS], w[2][NS]
+    double *Aloc = sm + 5 * NS;                             // (TR == 0) [rows_cap][ns] rows owned by this workgroup
+    const int lin = blockIdx.x, xcd_slot = lin >> 3;         // members of a matrix on one XCD, see k_tri_persist2
+    const int b = (lin & 7) * per_x + xcd_slot / G, g = xcd_slot % G, tid = threadIdx.x;
+    if (b >= nmat || xcd_slot / G >= per_x) return;
+    const int lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chn = (n + 63) >> 6, ns = 64 * chn;
+    double *A = A_ + (size_t)b * n * n;
+    double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
+    u64 *PX = XCH_ + (size_t)b * xch_stride;                // [2][n][2]
+    u64 *ROWX = PX + (size_t)4 * n;                         // [2][n][2]
+    if (tid == 0) s_fail = 0;
+    for (int i = tid; i < 5 * NS; i += blockDim.x) sm[i] = 0.0;
+    int r_end = 0;
+    for (int r = 0; r < rows_cap; ++r) r_end += ((g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC) < n) ? 1 : 0;
+    {
+        u64 *XID = ROWX + (size_t)4 * n;
+        if (tid == 0) {
+            const unsigned myx = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xF;      // HW_REG_XCC_ID[3:0]
+            __hip_atomic_store(&XID[g], ((u64)0x5EEDu << 32) | myx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int same = try_local ? 1 : 0;
+#pragma unroll 1
+            for (int u = 0; u < G; ++u) {
+                u64 w = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    w = __hip_atomic_load(&XID[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(w >> 32) == 0x5EEDu) break;
+                    if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if ((unsigned)(w & 0xF) != myx) same = 0;
+            }
+            s_xloc = same;
+            if (prof && b < 2) printf("[xcd] matrix %d member %d (workgroup %d): XCC %u, all members on one XCD: %d\n", b, g, lin, myx, same);
+        }
+        __syncthreads();
+    }
+    const bool xlocs = (s_xloc != 0);                        // stores XCD-local (sc0) when every member sits on one XCD; loads sc1
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(PX, 0, (int)((size_t)2 * n * 16), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(ROWX, 0, (int)((size_t)2 * n * 16), 0x00020000);
+    constexpr int TRR = TR > 0 ? TR : 1;
+    double areg[TRR][CH];
+    int gi_t[TRR];                                           // global row of slot t, -1 when the slot is empty
+    if constexpr (TR > 0) {
+#pragma unroll
+        for (int t = 0; t < TR; ++t) {
+            const int r = wid + NW * t;
+            const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+            gi_t[t] = (r < r_end) ? gi : -1;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; areg[t][q] = (r < r_end && jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
+        }
+        if (g == 0 && wid == 0) {                            // row 0: tag 1 in buffer 1 (step k = -1)
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16(rsR, (int)(((size_t)n + jj) * 16), areg[0][q], 1u, xlocs); }
+        }
+    } else {
+        gi_t[0] = -1;
+        for (int r = wid; r < r_end; r += NW) {
+            const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                if (q < chn) {
+                    const double a = (jj < n) ? A[(size_t)gi * n + jj] : 0.0;
+                    Aloc[r * ns + jj] = a;
+                    if (g == 0 && r == 0 && jj < n) put16(rsR, (int)(((size_t)n + jj) * 16), a, 1u, xlocs);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double tau = 0.0;                                        // (wave 0) tau of the reflector in sv
+    int vi0 = 0;                                             // v buffer of step k: (k + 1) % 3, kept incrementally
+    for (int k = -1; k <= n - 3; ++k) {
+        const int lo = k + 1, cur = k & 1, nxt = cur ^ 1;
+        const unsigned tag = (unsigned)(k + 2);
+        const int vi1 = (vi0 == 2) ? 0 : vi0 + 1;
+        double *sv = vb + vi0 * NS, *svn = vb + vi1 * NS, *sw = wb + nxt * NS;      // (nxt = (k + 1) & 1)
+        vi0 = vi1;
+        if (wid == 0) {
+            // ---- collect p = A v of step k and the pivot row lo: CH + CH tagged 16-byte loads per lane, all in flight
+            if (prof) t0 = wall_clock64();
+            u32x4 xp[CH], xr[CH];
+            unsigned spins = 0;
+            for (;;) {
+                asm volatile("" ::: "memory");               // buffer loads are ordinary loads to the compiler: re-issue every pass
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int jj = lane + 64 * q, jc = jj < n ? jj : n - 1;
+                    xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (cur * n + jc) * 16, 0, 16);      // aux 16 = sc1
+                    xp[q] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (cur * n + jc) * 16, 0, 16);
+                }
+                bool ok = true;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int jj = lane + 64 * q;
+                    const bool need = (jj >= lo) & (jj < n);
+                    const bool got = (xr[q][1] == tag) & (xr[q][3] == tag) & ((k < 0) | ((xp[q][1] == tag) & (xp[q][3] == tag)));
+                    ok = ok & (got | !need);
+                }
+#ifdef MOPT_P3_ABL_NOWAIT
+                ok = true;                                   // (timing ablation: one load pass, no waiting; results are garbage)
+#endif
+                if (ok) break;
+                if (++spins > LL_SPIN_LIMIT) { s_fail = 1; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (prof) { t1 = wall_clock64(); if (k >= 0) t_poll += t1 - t0; t0 = t1; }      // (k = -1: start-up skew, not a hand-off)
+            // ---- w_k = p + c v (p = tau A v, c = -tau/2 p.v), then the reflector of step k+1 from the updated row lo
+#ifdef MOPT_P3_ABL_NOPRO
+            if (k >= 0) goto p3_pro_done;                    // (timing ablation: no prologue arithmetic)
+#endif
+            {
+            const double v_lo = sv[lo];
+            double vq[CH], wq[CH], rq[CH];
+            double pvl = 0.0, plo_l = 0.0;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                const bool mq = (jj >= lo) & (jj < n);
+                vq[q] = sv[jj];                                                 // exact zero in dead and pad slots
+                const double pj = tau * __longlong_as_double((long long)((u64)xp[q][0] | ((u64)xp[q][2] << 32)));      // (tau = 0 at k = -1)
+                const double rj = __longlong_as_double((long long)((u64)xr[q][0] | ((u64)xr[q][2] << 32)));
+                wq[q] = mq ? pj : 0.0;
+                rq[q] = mq ? rj : 0.0;
+                pvl = fma(wq[q], vq[q], pvl);
+                plo_l = (jj == lo) ? wq[q] : plo_l;
+            }
+            const double c = -0.5 * tau * wave_sum(pvl);
+            const double w_lo = lane_bcast(plo_l, lo & 63) + c * v_lo;
+            double xl = 0.0, al_l = 0.0, dg_l = 0.0;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                wq[q] = fma(c, vq[q], wq[q]);                                  // w_j = p_j + c v_j
+                sw[jj] = wq[q];
+                rq[q] -= v_lo * wq[q] + w_lo * vq[q];                          // row lo after the rank-2 update of step k
+                al_l = (jj == lo + 1) ? rq[q] : al_l;
+                dg_l = (jj == lo) ? rq[q] : dg_l;
+                rq[q] = (jj >= lo + 2) ? rq[q] : 0.0;                          // the part the next reflector annihilates
+                xl = fma(rq[q], rq[q], xl);
+            }
+            const double xn2 = wave_sum(xl);
+            const double alpha = lane_bcast(al_l, (lo + 1) & 63);
+            const double diag = lane_bcast(dg_l, lo & 63);
+            const bool refl = (lo <= n - 3 && xn2 != 0.0);
+            const double bt = -copysign(sqrt(alpha * alpha + xn2), alpha);
+            const double betan = refl ? bt : alpha;
+            const double taun = refl ? (bt - alpha) / bt : 0.0;
+            const double scal = refl ? 1.0 / (alpha - bt) : 0.0;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int jj = lane + 64 * q;
+                const double vn = rq[q] * scal;
+                svn[jj] = vn;
+                if (g == 0 && jj >= lo + 2 && jj < n) A[(size_t)lo * n + jj] = vn;       // reflector of step k+1, dsytrd layout (row lo)
+            }
+            if (lane == 0) {
+                svn[lo + 1] = 1.0;                           // (behind the vector stores: LDS operations of a wave stay in order)
+                if (g == 0) { D[lo] = diag; E[lo] = betan; TAU[lo] = taun; if (lo == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; } }
+            }
+            tau = taun;
+            }
+#ifdef MOPT_P3_ABL_NOPRO
+        p3_pro_done:;
+#endif
+            if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
+        } else if (prof) t0 = wall_clock64();
+        lds_barrier();                                      // sw, svn (and the failure flag of the poll) complete
+        if (s_fail) break;
+        if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
+        // ---- main pass: rank-2 update of the rows with (v, w), then p_i = row_i . v' reduced inside the wave
+        {
+            double wj[CH], vj[CH], zj[CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; wj[q] = sw[jj]; vj[q] = sv[jj]; zj[q] = svn[jj]; }
+            if constexpr (TR > 0) {
+                double dots[TR];
+#ifdef MOPT_P3_ABL_NOMAIN
+#pragma unroll
+                for (int t = 0; t < TR; ++t) dots[t] = wj[t] + vj[t] + zj[t];      // (timing ablation: no row arithmetic)
+#else
+#pragma unroll
+                for (int t = 0; t < TR; ++t) {
+                    const int gic = gi_t[t] < 0 ? NS - 1 : (gi_t[t] < NS ? gi_t[t] : NS - 1);      // (empty slot: a pad entry, zero)
+                    const double vi = -sv[gic], wi = -sw[gic];                            // LDS broadcasts; zero for a dead row
+                    double d0 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) {
+                        areg[t][q] = fma(vi, wj[q], areg[t][q]);
+                        areg[t][q] = fma(wi, vj[q], areg[t][q]);
+                        d0 = fma(areg[t][q], zj[q], d0);
+                    }
+                    dots[t] = d0;
+                }
+#endif
+#pragma unroll
+                for (int t = 0; t < TR; ++t)
+                    if (gi_t[t] == lo + 1) {                                            // the next pivot row: publish it (wave-uniform)
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u, xlocs); }
+                    }
+#ifndef MOPT_P3_ABL_NORED
+#pragma unroll
+                for (int t = 0; t < TR; ++t) dots[t] = wave_sum63(dots[t]);             // independent chains; totals in lane 63
+#endif
+#pragma unroll
+                for (int t = 0; t < TR; ++t)
+                    if (lane == 63 && gi_t[t] > lo) put16(rsP, (nxt * n + gi_t[t]) * 16, dots[t], tag + 1u, xlocs);
+            } else {
+                const int m = (lo + 1) / TRI_RC, sft = (lo + 1) % TRI_RC;
+                const bool own_next = (m >= g && (m - g) % G == 0);                // this workgroup holds global row lo + 1
+                int r_first;
+                if (own_next) r_first = ((m - g) / G) * TRI_RC + sft;
+                else r_first = (m < g) ? 0 : ((m - g + G - 1) / G) * TRI_RC;
+                const int q0 = lo >> 6;                                             // first column chunk with a column >= lo
+                for (int rr = r_first + wid; rr < r_end; rr += NW) {
+                    const int gi = (g + (rr / TRI_RC) * G) * TRI_RC + (rr % TRI_RC);
+                    const double vi = -sv[gi], wi = -sw[gi];
+                    double *Ar = Aloc + rr * ns + lane;
+                    double a[CH];
+                    double d0 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) if (q >= q0 && q < chn) a[q] = Ar[64 * q];
+#pragma unroll
+                    for (int q = 0; q < CH; ++q)
+                        if (q >= q0 && q < chn) {
+                            a[q] = fma(vi, wj[q], a[q]);
+                            a[q] = fma(wi, vj[q], a[q]);
+                            d0 = fma(a[q], zj[q], d0);
+                        }
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) if (q >= q0 && q < chn) Ar[64 * q] = a[q];
+                    if (gi == lo + 1) {
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (q >= q0 && q < chn && jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, a[q], tag + 1u, xlocs); }
+                    }
+                    d0 = wave_sum63(d0);
+                    if (lane == 63) put16(rsP, (nxt * n + gi) * 16, d0, tag + 1u, xlocs);
+                }
+            }
+        }
+        if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
+    }
+    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = 0; q[3] = t_main; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
+    __syncthreads();
+    if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
+    {
+        const int gi_last = n - 1;
+        const int c = gi_last / TRI_RC;
+        if (c % G == g && !s_fail) {
+            const int r = (c / G) * TRI_RC + (gi_last % TRI_RC);
+            if constexpr (TR > 0) {
+#pragma unroll
+                for (int t = 0; t < TR; ++t)
+#pragma unroll
+                    for (int q = 0; q < CH; ++q)
+                        if (r == wid + NW * t && (n - 1) == lane + 64 * q) D[n - 1] = areg[t][q];
+            } else if (tid == 0) {
+                D[n - 1] = Aloc[r * ns + (n - 1)];
+            }
+        }
+    }
+}
+
 // D[n-1] after the last update (tiny)
 __global__ void k_tri_last(int n, const double *__restrict__ A_, double *__restrict__ D_) {
     const int b = blockIdx.x;
@@ -1578,7 +1869,12 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                          G <= ctx->num_cu && n <= 1024 && 4 * G + 4 <= n;
     // row-per-wave variant (k_tri_persist2): 16 waves, accp[16][n]
     int G2 = getenv("MOPT_TRI_G") ? atoi(getenv("MOPT_TRI_G")) : 8;
-    auto lds2_for = [&](int G_) { return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(5 + 16) * n) * 8; };
+    const bool want3 = !(getenv("MOPT_TRI_P3") && atoi(getenv("MOPT_TRI_P3")) == 0);      // row-dot variant k_tri_persist3 (default)
+    auto cht_for = [&]() { const int ch = (n + 63) / 64; return ch <= 6 ? ch : ch <= 8 ? 8 : ch <= 10 ? 10 : ch <= 12 ? 12 : 16; };
+    auto lds2_for = [&](int G_) {
+        if (want3) return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)5 * 64 * cht_for()) * 8;      // rows + v[3], w[2]
+        return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(5 + 16) * n) * 8;                          // rows + v, w, v', sums, accp[16]
+    };
     const bool g_forced = getenv("MOPT_TRI_G") != nullptr;      // experiment: register-resident rows with a forced group size
     while (!g_forced && G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
     // More workgroups per matrix when CUs are idle (few matrices per GPU) do not pay: measured at n = 300 with 4-16 matrices,
@@ -1588,19 +1884,81 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const int gmax = getenv("MOPT_TRI_GMAX") ? atoi(getenv("MOPT_TRI_GMAX")) : 8;
         while (!g_forced && 2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
     }
+    // (the members of a matrix are placed on ONE XCD: a group cannot be larger than its num_cu / 8 compute units)
     bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && (g_forced || lds2_for(G2) <= (size_t)ctx->lds_limit - 4096) &&
-                    G2 <= ctx->num_cu && n <= 1024 && 4 * G2 + 5 <= n;
+                    G2 <= ctx->num_cu / 8 && n <= 1024 && 4 * G2 + 5 <= n;
     if (persist2 && !getenv("MOPT_TRI_FORCEPERSIST")) {
         // Persistent kernel or one launch per Householder step?  Rough costs from the measurements in DESIGN.md section 5:
         // persistent: (4 + G/4) us per step and per group of num_cu/G matrices (6.2 us at G = 8; the exchange grows with G);
         // stepwise: all matrices at once, max(10 us, 40 % of the batch's bytes at 2.3 TB/s) per step (12 us at 32 x 300^2,
         // 30 us at 64 x 600^2, where the persistent form would need G = 128 and 32 launches: 416 ms against 18 ms).
+        // k_tri_persist3 (r01f, n = 300, G = 8: 2.9 us per step = 0.76 us main pass + 0.8 us prologue + hand-off): the main pass
+        // scales with the n^2 / G matrix entries of a workgroup, the prologue with the n / 64 column chunks of wave 0.
         const int per_ = ctx->num_cu / G2;
-        const double t_persist = (double)((batch + per_ - 1) / per_) * (4.0 + 0.25 * G2);
+        const double t_one = want3 ? 1.4 + 0.16 * ((n + 63) / 64) + 0.76 * ((double)n * n / G2) / 11250.0 : 4.0 + 0.25 * G2;
+        const double t_persist = (double)((batch + per_ - 1) / per_) * t_one;
         const double t_step = fmax(10.0, (double)batch * n * n * 8.0 * 0.4 / 2.3e6);
         if (t_step < t_persist) persist2 = false;
     }
-    if (persist2) {
+    if (persist2 && want3) {
+        mopt_scope sc(ctx, "eigh_tridiag", 1);
+        const int ch = (n + 63) / 64;
+        const int G = G2;
+        int rows = rows_for(G);
+        const int tr = (rows + 15) / 16;
+        const void *fn = nullptr;
+        const int cht = cht_for();                           // the CH the kernel is instantiated with
+        size_t lds_use = ((size_t)rows * (((n + 63) / 64) * 64) + (size_t)5 * 64 * cht) * 8;
+#define P3(C, T) ((const void *)k_tri_persist3<C, T>)
+#define P3T(C) (tr == 1 ? P3(C, 1) : tr == 2 ? P3(C, 2) : P3(C, 3))
+        if (!getenv("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
+            switch (ch <= 6 ? ch : 8) {
+                case 2: fn = P3T(2); break;
+                case 3: fn = P3T(3); break;
+                case 4: fn = P3T(4); break;
+                case 5: fn = P3T(5); break;
+                case 6: fn = (tr <= 2) ? (tr == 1 ? P3(6, 1) : P3(6, 2)) : nullptr; break;
+                case 8: fn = (tr <= 2) ? (tr == 1 ? P3(8, 1) : P3(8, 2)) : nullptr; break;
+            }
+            if (fn) lds_use = (size_t)5 * 64 * cht * 8;
+        }
+        if (!fn)
+            fn = ch <= 1 ? P3(1, 0) : ch <= 2 ? P3(2, 0) : ch <= 3 ? P3(3, 0) : ch <= 4 ? P3(4, 0) : ch <= 5 ? P3(5, 0) : ch <= 6 ? P3(6, 0)
+               : ch <= 8 ? P3(8, 0) : ch <= 10 ? P3(10, 0) : ch <= 12 ? P3(12, 0) : P3(16, 0);
+#undef P3T
+#undef P3
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+        long long *d_prof = nullptr;
+        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
+        const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
+        const size_t xwords = (size_t)8 * n + G;               // p vectors, pivot rows (two buffers each, two tagged words per value), XCC ids
+        MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
+        int try_local = getenv("MOPT_TRI_NOLOCAL") ? 0 : 1;
+        for (int b0 = 0; b0 < batch; b0 += per) {
+            const int nb_ = (batch - b0 < per) ? batch - b0 : per;
+            int per_x = (nb_ + 7) / 8;                          // matrices per XCD
+            int nmat = nb_;
+            int n_ = n, G_ = G;
+            double *pA = d_A + (size_t)b0 * n * n, *pD = d_D + (size_t)b0 * n, *pE = d_E + (size_t)b0 * n, *pT = d_TAU + (size_t)b0 * n;
+            u64 *pX = (u64 *)(d_Vt + (size_t)b0 * n * n);
+            size_t stride = (size_t)n * n;
+            int *pF = d_fail + b0;
+            long long *pP = d_prof ? d_prof + (size_t)b0 * G * 8 : nullptr;
+            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP, &nmat, &per_x, &try_local};
+            MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(8 * per_x * G), dim3(1024), args, lds_use, ctx->stream));
+        }
+        if (d_prof) {
+            std::vector<long long> h((size_t)batch * G * 8);
+            hipStreamSynchronize(ctx->stream);
+            hipMemcpy(h.data(), d_prof, h.size() * 8, hipMemcpyDeviceToHost);
+            hipFree(d_prof);
+            double sp = 0, sr = 0, sl = 0, sb = 0;
+            for (int i = 0; i < batch * G; ++i) { sp += h[8 * i]; sr += h[8 * i + 1]; sl += h[8 * i + 3]; sb += h[8 * i + 4]; }
+            const double f = 0.01 / (batch * G) / (n - 1);     // 100 MHz ticks -> us per step
+            fprintf(stderr, "[tri_prof3] n=%d G=%d per step (wave 0): poll %.2f us, prologue %.2f us, barrier %.2f us, main pass %.2f us; shader clock %.0f MHz\n", n, G,
+                    sp * f, sr * f, sb * f, sl * f, 100.0 * (double)h[5] / (double)(h[6] ? h[6] : 1));
+        }
+    } else if (persist2) {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         const int ch = (n + 63) / 64;
         const void *fn = nullptr;
