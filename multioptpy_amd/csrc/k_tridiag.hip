@@ -16,6 +16,7 @@
 // MOPT_TRI_FORCEPERSIST, MOPT_TRI_PERSIST1, MOPT_TRI_NOREG, MOPT_TRI_G, MOPT_TRI_GMAX, MOPT_TRI_SMALL, MOPT_INVIT_EXTRA,
 // MOPT_INVIT_DBG, MOPT_BT_DBG, MOPT_TRI_INJECT_FAIL.
 #include <cstdlib>
+#include <type_traits>
 #include <cstdio>
 #include <vector>
 #include "pipeline.h"
@@ -1015,28 +1016,33 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
     __syncthreads();
     double tau = 0.0;                                        // (wave 0) tau of the reflector in sv
     int vi0 = 0;                                             // v buffer of step k: (k + 1) % 3, kept incrementally
-    for (int k = -1; k <= n - 3; ++k) {
+    int k = -1;
+    // One Householder step, specialised at compile time on the first column chunk Q0 that still takes part: chunks below it
+    // hold dead columns only (and have done so for three steps, so all three v buffers and both w buffers already carry
+    // zeros there) and are not loaded, computed or stored.  Returns false when a hand-off timed out.
+    auto step = [&](auto q0c) -> bool {
+        constexpr int Q0 = decltype(q0c)::value;
         const int lo = k + 1, cur = k & 1, nxt = cur ^ 1;
         const unsigned tag = (unsigned)(k + 2);
         const int vi1 = (vi0 == 2) ? 0 : vi0 + 1;
         double *sv = vb + vi0 * NS, *svn = vb + vi1 * NS, *sw = wb + nxt * NS;      // (nxt = (k + 1) & 1)
         vi0 = vi1;
         if (wid == 0) {
-            // ---- collect p = A v of step k and the pivot row lo: CH + CH tagged 16-byte loads per lane, all in flight
+            // ---- collect p = A v of step k and the pivot row lo: tagged 16-byte loads, all in flight
             if (prof) t0 = wall_clock64();
             u32x4 xp[CH], xr[CH];
             unsigned spins = 0;
             for (;;) {
                 asm volatile("" ::: "memory");               // buffer loads are ordinary loads to the compiler: re-issue every pass
 #pragma unroll
-                for (int q = 0; q < CH; ++q) {
+                for (int q = Q0; q < CH; ++q) {
                     const int jj = lane + 64 * q, jc = jj < n ? jj : n - 1;
                     xr[q] = __builtin_amdgcn_raw_buffer_load_b128(rsR, (cur * n + jc) * 16, 0, 16);      // aux 16 = sc1
                     xp[q] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (cur * n + jc) * 16, 0, 16);
                 }
                 bool ok = true;
 #pragma unroll
-                for (int q = 0; q < CH; ++q) {
+                for (int q = Q0; q < CH; ++q) {
                     const int jj = lane + 64 * q;
                     const bool need = (jj >= lo) & (jj < n);
                     const bool got = (xr[q][1] == tag) & (xr[q][3] == tag) & ((k < 0) | ((xp[q][1] == tag) & (xp[q][3] == tag)));
@@ -1052,14 +1058,14 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
             if (prof) { t1 = wall_clock64(); if (k >= 0) t_poll += t1 - t0; t0 = t1; }      // (k = -1: start-up skew, not a hand-off)
             // ---- w_k = p + c v (p = tau A v, c = -tau/2 p.v), then the reflector of step k+1 from the updated row lo
 #ifdef MOPT_P3_ABL_NOPRO
-            if (k >= 0) goto p3_pro_done;                    // (timing ablation: no prologue arithmetic)
+            if (k < 0)
 #endif
             {
             const double v_lo = sv[lo];
             double vq[CH], wq[CH], rq[CH];
             double pvl = 0.0, plo_l = 0.0;
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
+            for (int q = Q0; q < CH; ++q) {
                 const int jj = lane + 64 * q;
                 const bool mq = (jj >= lo) & (jj < n);
                 vq[q] = sv[jj];                                                 // exact zero in dead and pad slots
@@ -1074,7 +1080,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
             const double w_lo = lane_bcast(plo_l, lo & 63) + c * v_lo;
             double xl = 0.0, al_l = 0.0, dg_l = 0.0;
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
+            for (int q = Q0; q < CH; ++q) {
                 const int jj = lane + 64 * q;
                 wq[q] = fma(c, vq[q], wq[q]);                                  // w_j = p_j + c v_j
                 sw[jj] = wq[q];
@@ -1093,7 +1099,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
             const double taun = refl ? (bt - alpha) / bt : 0.0;
             const double scal = refl ? 1.0 / (alpha - bt) : 0.0;
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
+            for (int q = Q0; q < CH; ++q) {
                 const int jj = lane + 64 * q;
                 const double vn = rq[q] * scal;
                 svn[jj] = vn;
@@ -1105,59 +1111,47 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
             }
             tau = taun;
             }
-#ifdef MOPT_P3_ABL_NOPRO
-        p3_pro_done:;
-#endif
             if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
         } else if (prof) t0 = wall_clock64();
         lds_barrier();                                      // sw, svn (and the failure flag of the poll) complete
-        if (s_fail) break;
+        if (s_fail) return false;
         if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
-        // ---- main pass: rank-2 update of the rows with (v, w), then p_i = row_i . v' reduced inside the wave
+        // ---- main pass: rank-2 update of the live rows with (v, w), then p_i = row_i . v' reduced inside the wave
         {
             double wj[CH], vj[CH], zj[CH];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; wj[q] = sw[jj]; vj[q] = sv[jj]; zj[q] = svn[jj]; }
+            for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; wj[q] = sw[jj]; vj[q] = sv[jj]; zj[q] = svn[jj]; }
             if constexpr (TR > 0) {
-                double dots[TR];
-#ifdef MOPT_P3_ABL_NOMAIN
-#pragma unroll
-                for (int t = 0; t < TR; ++t) dots[t] = wj[t] + vj[t] + zj[t];      // (timing ablation: no row arithmetic)
-#else
 #pragma unroll
                 for (int t = 0; t < TR; ++t) {
-                    const int gic = gi_t[t] < 0 ? NS - 1 : (gi_t[t] < NS ? gi_t[t] : NS - 1);      // (empty slot: a pad entry, zero)
-                    const double vi = -sv[gic], wi = -sw[gic];                            // LDS broadcasts; zero for a dead row
-                    double d0 = 0.0;
+                    if (gi_t[t] > lo) {                                                 // live row (wave-uniform)
+                        const int gi = gi_t[t];
+                        const double vi = -sv[gi], wi = -sw[gi];                        // LDS broadcasts
+                        double d0 = 0.0;
+#ifndef MOPT_P3_ABL_NOMAIN
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) {
-                        areg[t][q] = fma(vi, wj[q], areg[t][q]);
-                        areg[t][q] = fma(wi, vj[q], areg[t][q]);
-                        d0 = fma(areg[t][q], zj[q], d0);
-                    }
-                    dots[t] = d0;
-                }
+                        for (int q = Q0; q < CH; ++q) {
+                            areg[t][q] = fma(vi, wj[q], areg[t][q]);
+                            areg[t][q] = fma(wi, vj[q], areg[t][q]);
+                            d0 = fma(areg[t][q], zj[q], d0);
+                        }
 #endif
+                        if (gi == lo + 1) {                                             // the next pivot row: publish it
 #pragma unroll
-                for (int t = 0; t < TR; ++t)
-                    if (gi_t[t] == lo + 1) {                                            // the next pivot row: publish it (wave-uniform)
-#pragma unroll
-                        for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u, xlocs); }
-                    }
+                            for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u, xlocs); }
+                        }
 #ifndef MOPT_P3_ABL_NORED
-#pragma unroll
-                for (int t = 0; t < TR; ++t) dots[t] = wave_sum63(dots[t]);             // independent chains; totals in lane 63
+                        d0 = wave_sum63(d0);                                            // total in lane 63
 #endif
-#pragma unroll
-                for (int t = 0; t < TR; ++t)
-                    if (lane == 63 && gi_t[t] > lo) put16(rsP, (nxt * n + gi_t[t]) * 16, dots[t], tag + 1u, xlocs);
+                        if (lane == 63) put16(rsP, (nxt * n + gi) * 16, d0, tag + 1u, xlocs);
+                    }
+                }
             } else {
                 const int m = (lo + 1) / TRI_RC, sft = (lo + 1) % TRI_RC;
                 const bool own_next = (m >= g && (m - g) % G == 0);                // this workgroup holds global row lo + 1
                 int r_first;
                 if (own_next) r_first = ((m - g) / G) * TRI_RC + sft;
                 else r_first = (m < g) ? 0 : ((m - g + G - 1) / G) * TRI_RC;
-                const int q0 = lo >> 6;                                             // first column chunk with a column >= lo
                 for (int rr = r_first + wid; rr < r_end; rr += NW) {
                     const int gi = (g + (rr / TRI_RC) * G) * TRI_RC + (rr % TRI_RC);
                     const double vi = -sv[gi], wi = -sw[gi];
@@ -1165,19 +1159,19 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
                     double a[CH];
                     double d0 = 0.0;
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) if (q >= q0 && q < chn) a[q] = Ar[64 * q];
+                    for (int q = Q0; q < CH; ++q) if (q < chn) a[q] = Ar[64 * q];
 #pragma unroll
-                    for (int q = 0; q < CH; ++q)
-                        if (q >= q0 && q < chn) {
+                    for (int q = Q0; q < CH; ++q)
+                        if (q < chn) {
                             a[q] = fma(vi, wj[q], a[q]);
                             a[q] = fma(wi, vj[q], a[q]);
                             d0 = fma(a[q], zj[q], d0);
                         }
 #pragma unroll
-                    for (int q = 0; q < CH; ++q) if (q >= q0 && q < chn) Ar[64 * q] = a[q];
+                    for (int q = Q0; q < CH; ++q) if (q < chn) Ar[64 * q] = a[q];
                     if (gi == lo + 1) {
 #pragma unroll
-                        for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (q >= q0 && q < chn && jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, a[q], tag + 1u, xlocs); }
+                        for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn && jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, a[q], tag + 1u, xlocs); }
                     }
                     d0 = wave_sum63(d0);
                     if (lane == 63) put16(rsP, (nxt * n + gi) * 16, d0, tag + 1u, xlocs);
@@ -1185,6 +1179,24 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
             }
         }
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
+        return true;
+    };
+    for (; k <= n - 3; ++k) {
+        const int lo3 = k + 1 - 3;                           // a chunk is skipped once it has been dead for three steps
+        int qd = lo3 < 0 ? 0 : lo3 >> 6;
+        if (qd > CH - 1) qd = CH - 1;
+        bool ok = true;
+        switch (qd < 7 ? qd : 7) {
+            case 0: ok = step(std::integral_constant<int, 0>{}); break;
+            case 1: if constexpr (CH > 1) ok = step(std::integral_constant<int, 1>{}); break;
+            case 2: if constexpr (CH > 2) ok = step(std::integral_constant<int, 2>{}); break;
+            case 3: if constexpr (CH > 3) ok = step(std::integral_constant<int, 3>{}); break;
+            case 4: if constexpr (CH > 4) ok = step(std::integral_constant<int, 4>{}); break;
+            case 5: if constexpr (CH > 5) ok = step(std::integral_constant<int, 5>{}); break;
+            case 6: if constexpr (CH > 6) ok = step(std::integral_constant<int, 6>{}); break;
+            default: if constexpr (CH > 7) ok = step(std::integral_constant<int, 7>{}); break;
+        }
+        if (!ok) break;
     }
     if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = 0; q[3] = t_main; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
     __syncthreads();
