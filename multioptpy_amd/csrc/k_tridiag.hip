@@ -1227,13 +1227,23 @@ __global__ void k_tri_last(int n, const double *__restrict__ A_, double *__restr
 
 // ------------------------------------------------------------------------------------------------------------------
 // number of eigenvalues of the block (d[s..t), off-diagonals e2 = e^2) that are < x
+// The recurrence q_i = d_i - x - e_{i-1}^2 / q_{i-1} is one dependent chain per lane, and an IEEE division is ~12 dependent
+// instructions of it.  |q| >= pivmin >= DBL_MIN is a normal number and e^2 / pivmin <= 1 / DBL_MIN is finite, so the
+// quotient needs none of the scaling and fix-up steps: hardware reciprocal (v_rcp_f64, ~24 bits) plus two Newton steps
+// (relative error of a few 2^-53, i.e. a relative perturbation of e^2 of that size -- far inside the bisection tolerance).
+__device__ __forceinline__ double fast_rcp(double q) {
+    double r = __builtin_amdgcn_rcp(q);
+    r = fma(fma(-q, r, 1.0), r, r);
+    r = fma(fma(-q, r, 1.0), r, r);
+    return r;
+}
 __device__ __forceinline__ int sturm_count(const double *d, const double *e2, int s, int t, double x, double pivmin) {
     int cnt = 0;
     double q = d[s] - x;
     if (fabs(q) < pivmin) q = -pivmin;
     cnt += (q < 0.0);
     for (int i = s + 1; i < t; ++i) {
-        q = d[i] - x - e2[i - 1] / q;
+        q = fma(-e2[i - 1], fast_rcp(q), d[i] - x);
         if (fabs(q) < pivmin) q = -pivmin;
         cnt += (q < 0.0);
     }
