@@ -1338,21 +1338,33 @@ __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double 
 // (round-robin tournament), eigenvalues are Rayleigh quotients, V is orthogonal by construction.
 constexpr int TRI_SMALL = 32;
 __device__ __forceinline__ double quad_sum(double v) {
-    v += dpp_f64<0xB1, 0xF>(0.0, v);       // quad_perm [1,0,3,2]
-    v += dpp_f64<0x4E, 0xF>(0.0, v);       // quad_perm [2,3,0,1]
+    v += dpp_f64z<0xB1>(v);                // quad_perm [1,0,3,2]
+    v += dpp_f64z<0x4E>(v);                // quad_perm [2,3,0,1]
     return v;
 }
 // grid (n, batch): workgroup i works iff i is the first row of a small block.  Writes WT[s..t) and rows s..t-1 of Zt.
+// 1/sqrt(w) for a normal positive w: hardware estimate (v_rsq_f64) plus two Newton steps, no scaling or fix-up code
+__device__ __forceinline__ double fast_rsqrt(double w) {
+    double y = __builtin_amdgcn_rsq(w);
+    double e = fma(-(w * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    e = fma(-(w * y), y, 1.0);
+    y = fma(0.5 * y, e, y);
+    return y;
+}
 __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
                                                   const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_,
                                                   int *__restrict__ fail_) {
-    __shared__ double Gs[TRI_SMALL * TRI_SMALL], Vs[TRI_SMALL * TRI_SMALL];
+    // column stride mp = m | 1 doubles (odd): the 16 column pairs of a round then start in 16 different bank groups; with
+    // the natural stride of m = 32 doubles (256 B) every column starts in bank 0 and each LDS access is a 16-way conflict
+    __shared__ double Gs[TRI_SMALL * (TRI_SMALL + 1)], Vs[TRI_SMALL * (TRI_SMALL + 1)];
     __shared__ int s_rot;
     const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;
     const int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n;
     if (bstart[i0] != i0) return;
     const int s = i0, t = bend[i0], m = t - s;
     if (m < 2 || m > TRI_SMALL) return;
+    const int mp = m | 1;
     const double *D = D_ + (size_t)b * n + s, *E = E_ + (size_t)b * n + s;
     double *WT = WT_ + (size_t)b * n, *Zt = Zt_ + (size_t)b * n * n;
     // sigma = 1.0625 ||T||_inf: T + sigma I is positive definite with condition number <= 33
@@ -1361,15 +1373,16 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
     const double nrm = wave_max(rs);
     const double sigma = (nrm > 0.0) ? 1.0625 * nrm : 1.0;
     for (int e = lane; e < m * m; e += WAVE) {
-        const int c = e / m, r = e - c * m;                  // column-major: column c, row r
+        const int c = e / m, r = e - c * m;                  // column c, row r
         double g = 0.0;
         if (r == c) g = D[c] + sigma; else if (r == c + 1) g = E[c]; else if (r + 1 == c) g = E[r];
-        Gs[e] = g;
-        Vs[e] = (r == c) ? 1.0 : 0.0;
+        Gs[c * mp + r] = g;
+        Vs[c * mp + r] = (r == c) ? 1.0 : 0.0;
     }
     __syncthreads();
     const int me = (m + 1) & ~1, npair = me >> 1;            // an odd block gets a bye
     const int pi = lane >> 2, r4 = lane & 3;
+    constexpr int KP = TRI_SMALL / 4;                        // rows per lane of a pair
     bool converged = false;
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
         if (lane == 0) s_rot = 0;
@@ -1382,22 +1395,33 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
                 if (p >= m || q >= m) { p = -1; q = -1; }           // the bye
                 else if (p > q) { const int tt = p; p = q; q = tt; }
             }
+            const int pc = p < 0 ? 0 : p, qc = q < 0 ? 0 : q;
+            double *gp = Gs + pc * mp, *gq = Gs + qc * mp, *vp = Vs + pc * mp, *vq = Vs + qc * mp;
+            double x[KP], y[KP];
             double al = 0.0, be = 0.0, ga = 0.0;
-            if (p >= 0) {
-                const double *gp = Gs + p * m, *gq = Gs + q * m;
-                for (int k = r4; k < m; k += 4) { const double x = gp[k], y = gq[k]; al += x * x; be += y * y; ga += x * y; }
+#pragma unroll
+            for (int j = 0; j < KP; ++j) {
+                const int k = r4 + 4 * j;
+                const bool in = (p >= 0) & (k < m);
+                x[j] = in ? gp[k] : 0.0; y[j] = in ? gq[k] : 0.0;
+                al = fma(x[j], x[j], al); be = fma(y[j], y[j], be); ga = fma(x[j], y[j], ga);
             }
             al = quad_sum(al); be = quad_sum(be); ga = quad_sum(ga);
-            if (p >= 0 && ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
-                const double zeta = (be - al) / (2.0 * ga);
-                const double tn = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double c = 1.0 / sqrt(1.0 + tn * tn), sn = c * tn;
-                double *gp = Gs + p * m, *gq = Gs + q * m, *vp = Vs + p * m, *vq = Vs + q * m;
-                for (int k = r4; k < m; k += 4) {
-                    const double x = gp[k], y = gq[k];
-                    gp[k] = c * x - sn * y; gq[k] = sn * x + c * y;
-                    const double u = vp[k], w = vq[k];
-                    vp[k] = c * u - sn * w; vq[k] = sn * u + c * w;
+            // rotate when |ga| > 1e-15 sqrt(al be); the columns of G = (T + sigma I) V have norms within a factor 33 of each
+            // other, so every operand below is a normal number and the reciprocals need no scaling
+            if (p >= 0 && ga * ga > 1e-30 * (al * be)) {
+                const double zeta = (be - al) * fast_rcp(2.0 * ga);
+                const double w = fma(zeta, zeta, 1.0);
+                const double tn = copysign(fast_rcp(fabs(zeta) + w * fast_rsqrt(w)), zeta);
+                const double c = fast_rsqrt(fma(tn, tn, 1.0)), sn = c * tn;
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const int k = r4 + 4 * j;
+                    if (k < m) {
+                        gp[k] = c * x[j] - sn * y[j]; gq[k] = sn * x[j] + c * y[j];
+                        const double u = vp[k], wv = vq[k];
+                        vp[k] = c * u - sn * wv; vq[k] = sn * u + c * wv;
+                    }
                 }
                 if (r4 == 0) atomicAdd(&s_rot, 1);
             }
@@ -1410,11 +1434,11 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
     // eigenpairs: column c -> eigenvalue v.g / v.v - sigma, eigenvector v / |v| into row s + c of Zt (zero outside the block)
     for (int c = 0; c < m; ++c) {
         double vg = 0.0, vv = 0.0;
-        if (lane < m) { const double v = Vs[c * m + lane]; vg = v * Gs[c * m + lane]; vv = v * v; }
+        if (lane < m) { const double v = Vs[c * mp + lane]; vg = v * Gs[c * mp + lane]; vv = v * v; }
         vg = wave_sum(vg); vv = wave_sum(vv);
         double *z = Zt + (size_t)(s + c) * n;
         const double inv = 1.0 / sqrt(vv);
-        for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Vs[c * m + (i - s)] * inv : 0.0;
+        for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Vs[c * mp + (i - s)] * inv : 0.0;
         if (lane == 0) WT[s + c] = vg / vv - sigma;
     }
 }
