@@ -113,6 +113,8 @@ struct mopt_timer { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms
 struct mopt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;              // helper stream for work that is independent of the main chain (fork/join by events)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool timing = false;
     std::map<std::string, mopt_timer> timers;

@@ -17,6 +17,7 @@
 // MOPT_INVIT_DBG, MOPT_BT_DBG, MOPT_TRI_INJECT_FAIL.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 #include <cstdio>
 #include <vector>
 #include "pipeline.h"
@@ -1883,12 +1884,181 @@ __global__ void __launch_bounds__(256) k_tri_sort(int n, int npow2, const double
     if (threadIdx.x == 0) { info[2 * b] = 0; info[2 * b + 1] = bad | (fail_[b] ? 4 : 0); }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Blocked back-transformation on the FP64 matrix cores.  The reflectors are taken 16 at a time in compact WY form,
+//   H_{k0} H_{k0+1} ... H_{k0+15} = I - V T V^T      (dlarft, forward / columnwise; V = n x 16, T upper triangular),
+// so that for the eigenvectors z (rows of Zt)   z <- z - V (T (V^T z))   is three small matrix products, all of them
+// shaped for v_mfma_f64_16x16x4_f64 (operand maps as in k_gemm.hip: A: lane l holds A[l&15][l>>4]; B: B[l>>4][l&15];
+// C/D: col = l&15, row = (l>>4) + 4 reg).  A wave owns 16 eigenvectors for the whole sweep and keeps them in registers IN
+// the B-operand layout: lane (i = l&15, h = l>>4) holds z_i[4 r + h], r = 0 .. 4 NT - 1.  Per block of 16 reflectors:
+//   1.  W^T  = V^T Z^T :  acc[j][i] += V[4r+h][j] * z_i[4r+h]      one MFMA per r   (A from LDS, B = register r)
+//   2.  W'^T = T  W^T  :  4 MFMAs; register m of the result of 1 holds rows j = 4m + h, exactly the k-slice MFMA m needs as B
+//   3.  Z^T -= V W'^T  :  per 16-row tile tt 4 MFMAs with A = -V[16tt + (l&15)][4m + h], B = register m of 2, and the
+//       accumulator = registers 4tt .. 4tt+3 of z: row (l>>4) + 4 reg of the tile is component 4 (4tt + reg) + h -- the layout z is kept in.
+// The dot products, their reductions and the updates of the VALU kernel (2 x 19 FMAs + a 12-instruction DPP reduction per
+// reflector and vector) become ~1 MFMA per 64 multiply-adds; no cross-lane instruction is left.
+
+template <int... I, class F>
+__device__ __forceinline__ void static_for_desc(std::integer_sequence<int, I...>, F &&f) {
+    (f(std::integral_constant<int, (int)sizeof...(I) - 1 - I>{}), ...);         // f(N-1), f(N-2), ..., f(0)
+}
+
+// T factors: grid (NB, batch), 256 threads.  T[beta] is stored row-major 16 x 16 (zeros below the diagonal).
+__global__ void __launch_bounds__(256) k_tri_larft(int n, int NB, const double *__restrict__ A_, const double *__restrict__ TAU_,
+                                                   double *__restrict__ T_) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int ldv = n | 1;
+    double *Vs = sm;                                         // [16][ldv]
+    double *Gm = sm + (size_t)16 * ldv, *Tm = Gm + 16 * 17, *st = Tm + 16 * 17;     // Gram matrix, T, tau
+    const int b = blockIdx.y, beta = blockIdx.x, tid = threadIdx.x, k0 = 16 * beta;
+    const double *A = A_ + (size_t)b * n * n, *TAU = TAU_ + (size_t)b * n;
+    for (int e = tid; e < 16 * n; e += 256) {
+        const int c = e / n, i = e - c * n, k = k0 + c;
+        double v = 0.0;
+        if (k <= n - 3) { if (i == k + 1) v = 1.0; else if (i > k + 1) v = A[(size_t)k * n + i]; }
+        Vs[c * ldv + i] = v;
+    }
+    if (tid < 16) st[tid] = (k0 + tid <= n - 3) ? TAU[k0 + tid] : 0.0;
+    __syncthreads();
+    {
+        const int c1 = tid >> 4, c2 = tid & 15;
+        double g = 0.0;
+        if (c1 < c2) { const double *x = Vs + c1 * ldv, *y = Vs + c2 * ldv; for (int i = k0 + c2 + 1; i < n; ++i) g = fma(x[i], y[i], g); }
+        Gm[c1 * 17 + c2] = g;
+        Tm[c1 * 17 + c2] = 0.0;
+    }
+    __syncthreads();
+    // T(0:c, c) = -tau_c T(0:c, 0:c) (V(:, 0:c)^T v_c),  T(c, c) = tau_c
+    for (int c = 0; c < 16; ++c) {
+        if (tid < c) {
+            double a = 0.0;
+            for (int j = tid; j < c; ++j) a = fma(Tm[tid * 17 + j], Gm[j * 17 + c], a);
+            Tm[tid * 17 + c] = -st[c] * a;
+        } else if (tid == c) Tm[c * 17 + c] = st[c];
+        __syncthreads();
+    }
+    T_[((size_t)b * NB + beta) * 256 + tid] = Tm[(tid >> 4) * 17 + (tid & 15)];
+}
+
+template <int NT, int WPW>
+__global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, const double *__restrict__ A_, const double *__restrict__ T_,
+                                                            double *__restrict__ Zt_, const int *__restrict__ bend_) {
+    constexpr int LEN = 16 * NT;                                           // padded vector length
+    constexpr int LDV = LEN + ((2 - LEN % 32 + 32) % 32);                   // = 2 mod 32: the 16 x 2 operand reads of step 1 hit 32 different bank pairs
+    constexpr int NTHR = 64 * WPW, NLD = (16 * LEN + NTHR - 1) / NTHR, NTL = 256 / NTHR;      // staging loads per thread: reflectors, T
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *Vs = sm;                                                        // [16][LDV]
+    double *Ts = sm + (size_t)16 * LDV;                                     // [16][17]
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int li = lane & 15, lh = lane >> 4;
+    const double *A = A_ + (size_t)b * n * n;
+    const double *Tg = T_ + (size_t)b * NB * 256;
+    double *Zt = Zt_ + (size_t)b * n * n;
+    const int j0 = blockIdx.x * (16 * WPW) + wid * 16;                              // first eigenvector of this wave
+    double z[4 * NT];
+#pragma unroll
+    for (int r = 0; r < 4 * NT; ++r) { const int k = 4 * r + lh; z[r] = (j0 + li < n && k < n) ? Zt[(size_t)(j0 + li) * n + k] : 0.0; }
+    // an eigenvector lives on its unreduced block [s, t) of the tridiagonal: reflectors k >= t - 1 do not touch it
+    int beta_first = NB - 1;
+    if (bend_) {
+        int tmax = 0;
+        for (int q = 0; q < 16 * WPW; ++q) { const int jj = blockIdx.x * (16 * WPW) + q; if (jj < n) { const int t = bend_[(size_t)b * n + jj]; tmax = t > tmax ? t : tmax; } }
+        const int kf = tmax - 2 < 0 ? 0 : tmax - 2;
+        beta_first = (kf / 16 < NB - 1) ? kf / 16 : NB - 1;
+    }
+    auto fetch = [&](int beta, double (&pre)[NLD], double (&pt)[NTL]) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int e = tid + NTHR * m, c = e / LEN, i = e - c * LEN, k = 16 * beta + c;
+            double v = 0.0;
+            if (beta >= 0 && c < 16 && k <= n - 3) { if (i == k + 1) v = 1.0; else if (i > k + 1 && i < n) v = A[(size_t)k * n + i]; }
+            pre[m] = v;
+        }
+#pragma unroll
+        for (int m = 0; m < NTL; ++m) pt[m] = (beta >= 0) ? Tg[(size_t)beta * 256 + tid + NTHR * m] : 0.0;
+    };
+    auto stage = [&](const double (&pre)[NLD], const double (&pt)[NTL]) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) { const int e = tid + NTHR * m, c = e / LEN, i = e - c * LEN; if (c < 16) Vs[c * LDV + i] = pre[m]; }
+#pragma unroll
+        for (int m = 0; m < NTL; ++m) { const int e = tid + NTHR * m; Ts[(e >> 4) * 17 + (e & 15)] = pt[m]; }
+    };
+    double pre[NLD], pt[NTL];
+    fetch(beta_first, pre, pt);
+    // The sweep over the blocks is unrolled at compile time (block BETA touches components >= 16 BETA + 1 only, i.e. the
+    // 16-row tiles tt >= BETA: half of the MFMAs of the rectangular form act on structural zeros), so every index into z
+    // is static; blocks above beta_first are skipped by a uniform test.
+    static_for_desc(std::make_integer_sequence<int, NT>{}, [&](auto bc) {
+        constexpr int BETA = decltype(bc)::value;
+        if (BETA <= beta_first) {
+            __syncthreads();                                                // the previous block's operand reads are done
+            stage(pre, pt);
+            __syncthreads();
+            fetch(BETA - 1, pre, pt);                                       // in flight during the arithmetic below
+            // 1. W^T = V^T Z^T   (two accumulators: the MFMAs of one chain depend on each other)
+            // (the LDS operands are requested one group of four MFMAs ahead: a read issued right in front of its MFMA leaves
+            // the matrix pipe idle for the LDS latency)
+            d4 w0 = {0.0, 0.0, 0.0, 0.0}, w1 = {0.0, 0.0, 0.0, 0.0};
+            const double *va = Vs + li * LDV + lh;
+            const double *vb = Vs + lh * LDV + li;
+            double tq[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) tq[m] = Ts[li * 17 + 4 * m + lh];
+            {
+                double ac[4], an[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) ac[u] = va[4 * (4 * BETA + u)];
+#pragma unroll
+                for (int tt = BETA; tt < NT; ++tt) {
+                    if (tt + 1 < NT) {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) an[u] = va[4 * (4 * (tt + 1) + u)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);       // keep the reads ahead of the MFMAs (the scheduler sinks them to their uses)
+                    w0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[0], z[4 * tt], w0, 0, 0, 0);
+                    w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[1], z[4 * tt + 1], w1, 0, 0, 0);
+                    w0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[2], z[4 * tt + 2], w0, 0, 0, 0);
+                    w1 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[3], z[4 * tt + 3], w1, 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) ac[u] = an[u];
+                }
+            }
+            w0 += w1;
+            // 2. W'^T = T W^T
+            d4 x = {0.0, 0.0, 0.0, 0.0};
+            double bc[4], bn[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) bc[m] = vb[(size_t)4 * m * LDV + 16 * BETA];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) x = __builtin_amdgcn_mfma_f64_16x16x4f64(tq[m], w0[m], x, 0, 0, 0);
+            // 3. Z^T -= V W'^T
+#pragma unroll
+            for (int tt = BETA; tt < NT; ++tt) {
+                if (tt + 1 < NT) {
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) bn[m] = vb[(size_t)4 * m * LDV + 16 * (tt + 1)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                d4 c = {z[4 * tt], z[4 * tt + 1], z[4 * tt + 2], z[4 * tt + 3]};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) c = __builtin_amdgcn_mfma_f64_16x16x4f64(-bc[m], x[m], c, 0, 0, 0);
+                z[4 * tt] = c[0]; z[4 * tt + 1] = c[1]; z[4 * tt + 2] = c[2]; z[4 * tt + 3] = c[3];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) bc[m] = bn[m];
+            }
+        }
+    });
+#pragma unroll
+    for (int r = 0; r < 4 * NT; ++r) { const int k = 4 * r + lh; if (j0 + li < n && k < n) Zt[(size_t)(j0 + li) * n + k] = z[r]; }
+}
+
 }  // namespace mopt
 
 static int g_tri_attr = 0, g_tri_attr2 = 0;
 
 // A is destroyed (reflectors are left in its rows).  Work arrays: d_D, d_E, d_TAU, d_WT, d_onenrm: batch*n doubles each;
-// d_Z2: batch*n*n doubles (scratch copy of the eigenvectors for the cluster orthogonalisation).  d_bstart, d_bend: batch*n ints; d_cstart: 2*batch*n ints (tight and loose cluster tables); d_ncl: 2*batch ints; d_fail: batch ints.
+// d_Z2: batch*(n*n + MOPT_TRI_T_DOUBLES(n)) doubles (scratch copy of the eigenvectors for the cluster orthogonalisation, then the T factors of the blocked back-transformation).  d_bstart, d_bend: batch*n ints; d_cstart: 2*batch*n ints (tight and loose cluster tables); d_ncl: 2*batch ints; d_fail: batch ints.
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
                              double *d_W, int *d_perm, int *d_info, double *d_Z2) {
@@ -2108,6 +2278,19 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         hipLaunchKernelGGL(k_tridiag, dim3(batch), dim3(1024), (size_t)19 * n * 8, ctx->stream, n, getenv("MOPT_TRI_DBG") ? atoi(getenv("MOPT_TRI_DBG")) : 0, d_A, d_D, d_E, d_TAU);
     }
+    // Blocked back-transformation on the matrix cores (the eigenvectors of a wave live in registers, 4 * ceil(n / 16) doubles per
+    // lane: up to n = 384 without spilling).  Its T factors depend on the reflectors only, so k_tri_larft runs on the side
+    // stream while the main stream finds eigenvalues and eigenvectors of the tridiagonal (latency-bound kernels with idle CUs).
+    const int nt16 = (n + 15) / 16;
+    const bool bt_mfma = !(getenv("MOPT_BT_MFMA") && atoi(getenv("MOPT_BT_MFMA")) == 0) && nt16 <= 24 && n >= 16;
+    const int bt_NB = (n - 2 + 15) / 16;
+    double *bt_T = d_Z2 + (size_t)batch * n * n;
+    if (bt_mfma) {
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_tri_larft, dim3(bt_NB, batch), dim3(256), ((size_t)16 * (n | 1) + 2 * 16 * 17 + 16) * 8, ctx->side, n, bt_NB, d_A, d_TAU, bt_T);
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+    }
     int small_max = getenv("MOPT_TRI_SMALL") ? atoi(getenv("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
     if (small_max > TRI_SMALL) small_max = TRI_SMALL;
     if (small_max < 0) small_max = 0;
@@ -2134,7 +2317,23 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                                d_Vt, d_Z2, small_max);
         }
     }
-    {
+    if (bt_mfma) {
+        // blocked form on the matrix cores; the T factors (behind the n^2 doubles per matrix of d_Z2) were formed on the side stream
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        mopt_scope sc(ctx, "eigh_backtrans", 1);
+        const int NB = bt_NB;
+        double *d_T = bt_T;
+        // 4 waves (16 eigenvectors each) per workgroup; measured with 2 / 1 waves (twice / four times the staging work per
+        // thread, 320 / 608 workgroups): 0.58 / 1.11 ms against 0.148 ms
+#define BTW(NT_, W_) do { constexpr int LEN_ = 16 * NT_, LDV_ = LEN_ + ((2 - LEN_ % 32 + 32) % 32); const size_t lds = ((size_t)16 * LDV_ + 16 * 17) * 8; \
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_backtrans_mfma<NT_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024)); \
+        hipLaunchKernelGGL((k_tri_backtrans_mfma<NT_, W_>), dim3((n + 16 * W_ - 1) / (16 * W_), batch), dim3(64 * W_), lds, ctx->stream, n, NB, d_A, d_T, d_Vt, (const int *)d_bend); } while (0)
+#define BTM(NT_) BTW(NT_, 4)
+        if (nt16 <= 4) BTM(4); else if (nt16 <= 8) BTM(8); else if (nt16 <= 12) BTM(12); else if (nt16 <= 16) BTM(16); else if (nt16 <= 19) BTM(19);
+        else BTM(24);
+#undef BTM
+#undef BTW
+    } else {
         mopt_scope sc(ctx, "eigh_backtrans", 1);
         const int np16 = (n + 15) / 16;
         const dim3 g((n + 15) / 16, batch);

@@ -23,6 +23,14 @@ extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
     c->device = device;
     if (hipSetDevice(device) != hipSuccess) { delete c; return MOPT_E_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MOPT_E_DEVICE; }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev_fork) hipEventDestroy(c->ev_fork);
+        if (c->side) hipStreamDestroy(c->side);
+        hipStreamDestroy(c->stream);
+        delete c;
+        return MOPT_E_DEVICE;
+    }
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) c->lds_limit = v;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && v > 0) c->num_cu = v;
@@ -36,6 +44,9 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto &kv : ctx->timers) for (auto &e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (ctx->arena) hipFree(ctx->arena);
+    hipStreamSynchronize(ctx->side);
+    hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join);
+    hipStreamDestroy(ctx->side);
     hipStreamDestroy(ctx->stream);
     delete ctx;
     return MOPT_OK;
@@ -155,7 +166,7 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     hipSetDevice(ctx->device);
     const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
     DBuf dA, dG, dVt, dV, dsig, drot, dW, dperm, dinfo;
-    TRY(dA.alloc(ctx, nn)); TRY(dG.alloc(ctx, nn)); TRY(dVt.alloc(ctx, nn)); TRY(dV.alloc(ctx, nn));
+    TRY(dA.alloc(ctx, nn)); TRY(dG.alloc(ctx, nn + (size_t)batch * MOPT_TRI_T_DOUBLES(n) * sizeof(double))); TRY(dVt.alloc(ctx, nn)); TRY(dV.alloc(ctx, nn));
     TRY(dsig.alloc(ctx, batch * sizeof(double))); TRY(drot.alloc(ctx, (size_t)batch * (JAC_MAX_SWEEPS + 1) * sizeof(int)));
     TRY(dW.alloc(ctx, nv)); TRY(dperm.alloc(ctx, (size_t)batch * n * sizeof(int))); TRY(dinfo.alloc(ctx, (size_t)batch * 2 * sizeof(int)));
     H2D(ctx, dA.p, A, nn);

@@ -11,6 +11,8 @@ constexpr int JAC_MAX_SWEEPS = 30;
 }
 
 // scratch of the reduction-route eigen-solver (k_tridiag.hip)
+// doubles per matrix behind the n^2 of Z2: the 16 x 16 T factors of the blocked back-transformation, ceil((n - 2) / 16) of them
+#define MOPT_TRI_T_DOUBLES(n) ((size_t)16 * ((size_t)(n) + 16))
 struct TriScratch { double *D, *E, *TAU, *WT, *onenrm, *Z2; int *bstart, *bend, *cstart, *ncl, *fail; };
 
 // Device workspace of one batched RSIRFO.run (all pointers are device pointers).

@@ -45,7 +45,7 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
     tri.onenrm = (double *)take(nv * 8);
     tri.bstart = (int *)take(nv * 4); tri.bend = (int *)take(nv * 4); tri.cstart = (int *)take(2 * nv * 4);     // tight + loose cluster tables
     tri.ncl = (int *)take((size_t)2 * batch * 4); tri.fail = (int *)take((size_t)batch * 4);
-    tri.Z2 = (double *)take((size_t)batch * n * n * 8);
+    tri.Z2 = (double *)take((size_t)batch * ((size_t)n * n + MOPT_TRI_T_DOUBLES(n)) * 8);     // Loewdin scratch + T factors
     return MOPT_OK;
 }
 
