@@ -19,7 +19,7 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
     tot += 3 * al((size_t)batch * 8) + al((size_t)batch * 8 * 8);
     tot += al((size_t)batch * 2 * 4) + al((size_t)batch * (mopt::JAC_MAX_SWEEPS + 1) * 4) + 2 * al((size_t)batch * 4);
     tot += 5 * al(nv * 8) + 2 * al(nv * 4) + al(2 * nv * 4) + al((size_t)2 * batch * 4) + al((size_t)batch * 4);      // reduction-route eigen-solver scratch
-    tot += al((size_t)batch * n * n * 8);                                                                                // ... and its second eigenvector buffer
+    tot += al((size_t)batch * ((size_t)n * n + MOPT_TRI_T_DOUBLES(n)) * 8);                                              // ... its second eigenvector buffer and the T factors
     tot += al(batch * sizeof(mopt::UpdateCoef)) + al(batch * sizeof(mopt_rsirfo_params)) + al(batch * sizeof(mopt_rsirfo_state));
     if (hipMalloc(&block, tot) != hipSuccess) { c->err = "hipMalloc failed (RSIRFO workspace)"; block = nullptr; return MOPT_E_NOMEM; }
     char *p = (char *)block;
