@@ -237,10 +237,11 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
                (tp1 - tp0) * 0.01, (tp2 - tp1) * 0.01, (tp3 - tp2) * 0.01, rr.branch, rr.secular_iters0, (wall_clock64() - tp3) * 0.01);
 }
 
-// out[b][j] = - sum_i coef[b][i] Vt[b][i][j]     grid (ceil(n/64), batch), block 256
-__global__ void __launch_bounds__(256) k_backtransform(int n, const double *__restrict__ Vt, const double *__restrict__ coef,
-                                                       const int *__restrict__ einfo, double *__restrict__ out) {
-    __shared__ double part[4][64];
+// out[b][j] = - sum_i coef[b][i] Vt[b][i][j]     grid (ceil(n/64), batch), block 1024: 16 waves share the rows of a
+// 64-column strip (four independent loads in flight per wave: the kernel is a latency chain of row reads, not a bandwidth user)
+__global__ void __launch_bounds__(1024) k_backtransform(int n, const double *__restrict__ Vt, const double *__restrict__ coef,
+                                                        const int *__restrict__ einfo, double *__restrict__ out) {
+    __shared__ double part[16][64];
     const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + lane;
     const double *c = coef + (size_t)b * n;
@@ -249,16 +250,25 @@ __global__ void __launch_bounds__(256) k_backtransform(int n, const double *__re
         return;
     }
     const double *V = Vt + (size_t)b * n * n;
-    double acc = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     if (j < n) {
-        for (int i = wid; i < n; i += 4) {
-            const double ci = c[i];
-            if (ci != 0.0) acc += ci * V[(size_t)i * n + j];
+        int i = wid;
+        for (; i + 48 < n; i += 64) {
+            const double c0 = c[i], c1 = c[i + 16], c2 = c[i + 32], c3 = c[i + 48];
+            const double v0 = V[(size_t)i * n + j], v1 = V[(size_t)(i + 16) * n + j], v2 = V[(size_t)(i + 32) * n + j], v3 = V[(size_t)(i + 48) * n + j];
+            a0 = fma(c0, c0 != 0.0 ? v0 : 0.0, a0); a1 = fma(c1, c1 != 0.0 ? v1 : 0.0, a1);      // (a zero coefficient drops its vector whatever it holds)
+            a2 = fma(c2, c2 != 0.0 ? v2 : 0.0, a2); a3 = fma(c3, c3 != 0.0 ? v3 : 0.0, a3);
         }
+        for (; i < n; i += 16) { const double ci = c[i]; a0 = fma(ci, ci != 0.0 ? V[(size_t)i * n + j] : 0.0, a0); }
     }
-    part[wid][lane] = acc;
+    part[wid][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (wid == 0 && j < n) out[(size_t)b * n + j] = -(part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+    if (wid == 0 && j < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][lane];
+        out[(size_t)b * n + j] = -t;
+    }
 }
 
 }  // namespace mopt
@@ -279,7 +289,7 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
     hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_gp, d_einfo, d_gt_all);
     hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(64), lds, ctx->stream, n, d_params, d_states, d_W, d_perm, d_einfo,
                        d_gt_all, d_Bg, d_Be, d_coef, d_coefout, getenv("MOPT_RFO_DBG") ? 1 : 0);
-    hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_coefout, d_einfo, d_step);
+    hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(1024), 0, ctx->stream, n, d_Vt, d_coefout, d_einfo, d_step);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }
@@ -293,7 +303,7 @@ int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const d
 
 int mopt_launch_backtransform(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_coef, const int *d_einfo, double *d_out) {
     using namespace mopt;
-    hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_coef, d_einfo, d_out);
+    hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(1024), 0, ctx->stream, n, d_Vt, d_coef, d_einfo, d_out);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

@@ -1387,6 +1387,7 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
     bool converged = false;
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
         if (lane == 0) s_rot = 0;
+        double cos2max = 0.0;                                // largest squared cosine between two columns met in this sweep
         __syncthreads();
         for (int r = 0; r < me - 1; ++r) {
             int p = -1, q = -1;
@@ -1411,6 +1412,7 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
             // rotate when |ga| > 1e-15 sqrt(al be); the columns of G = (T + sigma I) V have norms within a factor 33 of each
             // other, so every operand below is a normal number and the reciprocals need no scaling
             if (p >= 0 && ga * ga > 1e-30 * (al * be)) {
+                cos2max = fmax(cos2max, ga * ga * fast_rcp(al * be));
                 const double zeta = (be - al) * fast_rcp(2.0 * ga);
                 const double w = fma(zeta, zeta, 1.0);
                 const double tn = copysign(fast_rcp(fabs(zeta) + w * fast_rsqrt(w)), zeta);
@@ -1428,7 +1430,9 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
             }
             __syncthreads();
         }
-        converged = (s_rot == 0);
+        // Jacobi converges quadratically: a sweep whose columns all met at cosines below 1e-8 leaves them at ~1e-16, the
+        // rotation threshold itself -- the sweeps that would only confirm this (one or two of five to seven) are not run
+        converged = (s_rot == 0) || (wave_max(cos2max) < 1e-16);
         __syncthreads();
     }
     if (!converged && lane == 0) atomicAdd(&fail_[b], 1);
@@ -1854,7 +1858,7 @@ __global__ void __launch_bounds__(256) k_tri_backtrans(int n, const double *__re
 }
 
 // ascending sort of WT -> W, perm (same contract as k_jac_finalize); dynamic LDS npow2 * 12 bytes
-__global__ void __launch_bounds__(256) k_tri_sort(int n, int npow2, const double *__restrict__ WT_, const int *__restrict__ fail_,
+__global__ void __launch_bounds__(1024) k_tri_sort(int n, int npow2, const double *__restrict__ WT_, const int *__restrict__ fail_,
                                                   double *__restrict__ W, int *__restrict__ perm, int *__restrict__ info) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *key = sm;
@@ -1866,21 +1870,30 @@ __global__ void __launch_bounds__(256) k_tri_sort(int n, int npow2, const double
         else { key[i] = INFINITY; idx[i] = -1; }
     }
     bad = __syncthreads_or(bad);
-    for (int kk = 2; kk <= npow2; kk <<= 1) {
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < npow2; i += blockDim.x) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const bool up = ((i & kk) == 0);
-                    const double ki = key[i], kl = key[l];
-                    const bool gt = (ki > kl) || (ki == kl && idx[i] > idx[l]) || (ki != ki && kl == kl);
-                    if (gt == up) { key[i] = kl; key[l] = ki; const int t = idx[i]; idx[i] = idx[l]; idx[l] = t; }
-                }
+    // rank sort: entry i goes to position #{j : key_j before key_i} (ascending, ties by index, NaN last) -- every thread walks
+    // the keys as LDS broadcasts, no exchange stages and no further barrier (the bitonic network needed 45 of them at n = 300)
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double ki = key[i];
+        int rank = 0;
+        if (!bad) {                                          // all keys finite: "before" is <= below i and < above it
+            int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            int j = 0;
+            for (; j + 3 < i; j += 4) { r0 += key[j] <= ki; r1 += key[j + 1] <= ki; r2 += key[j + 2] <= ki; r3 += key[j + 3] <= ki; }
+            for (; j < i; ++j) r0 += key[j] <= ki;
+            j = i + 1;
+            for (; j + 3 < n; j += 4) { r0 += key[j] < ki; r1 += key[j + 1] < ki; r2 += key[j + 2] < ki; r3 += key[j + 3] < ki; }
+            for (; j < n; ++j) r0 += key[j] < ki;
+            rank = (r0 + r1) + (r2 + r3);
+        } else {
+            const bool inan = (ki != ki);
+            for (int j = 0; j < n; ++j) {
+                const double kj = key[j];
+                const bool before = inan ? ((kj == kj) || j < i) : ((kj < ki) || (kj == ki && j < i));
+                rank += before ? 1 : 0;
             }
-            __syncthreads();
         }
+        W[(size_t)b * n + rank] = ki; perm[(size_t)b * n + rank] = i;
     }
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { W[(size_t)b * n + i] = key[i]; perm[(size_t)b * n + i] = idx[i]; }
     if (threadIdx.x == 0) { info[2 * b] = 0; info[2 * b + 1] = bad | (fail_[b] ? 4 : 0); }
 }
 
@@ -2352,7 +2365,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         mopt_scope sc(ctx, "eigh_final", 1);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
-        hipLaunchKernelGGL(k_tri_sort, dim3(batch), dim3(256), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_WT, d_fail, d_W, d_perm, d_info);
+        hipLaunchKernelGGL(k_tri_sort, dim3(batch), dim3(n <= 256 ? 256 : n <= 512 ? 512 : 1024), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_WT, d_fail, d_W, d_perm, d_info);
     }
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
