@@ -394,11 +394,8 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
         b->have_vecs = false;
     }
     const bool have_prev = b->have_prev && optimize_num != 0;
-    {
-        std::vector<int> upd(count, have_prev ? 1 : 0);
-        MOPT_HIP_TRY(ctx, hipMemcpyAsync(wk.do_update, upd.data(), count * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));     // upd is a stack object
-    }
+    // (a fill node, not a copy from a host buffer: the step enqueues without waiting for the stream)
+    MOPT_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)wk.do_update, have_prev ? 1 : 0, (size_t)count, ctx->stream));
     // 1. NEB force on the whole band (every shard needs all of F for FIRE's global switch)
     BTRY(mopt_launch_bneb_force(ctx, I, N, 0, I, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau));
     // 2. Ayala curvature correction of the owned interior images

@@ -289,8 +289,18 @@ int mopt_launch_sym_add(mopt_ctx *ctx, int n, int batch, const double *d_H, cons
     return MOPT_OK;
 }
 
-int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp, int variant) {
+// side_stream: the projected gradient depends on g and x only and is not needed before the RFO stage, so the pipeline runs
+// it on the helper stream next to the Hessian chain (fork here, join in front of k_vtg); it is then not part of a timed family.
+int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp, int variant, bool side_stream) {
     using namespace mopt;
+    if (side_stream) {
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork2, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork2, 0));
+        hipLaunchKernelGGL(k_proj_grad, dim3(batch), dim3(256), (size_t)7 * n * sizeof(double), ctx->side, n, variant, d_g, d_X, d_gp);
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join2, ctx->side));
+        MOPT_HIP_TRY(ctx, hipGetLastError());
+        return MOPT_OK;
+    }
     mopt_scope sc(ctx, "project", 1);
     hipLaunchKernelGGL(k_proj_grad, dim3(batch), dim3(256), (size_t)7 * n * sizeof(double), ctx->stream, n, variant, d_g, d_X, d_gp);
     MOPT_HIP_TRY(ctx, hipGetLastError());

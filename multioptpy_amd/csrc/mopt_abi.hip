@@ -24,8 +24,12 @@ extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) { delete c; return MOPT_E_DEVICE; }
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return MOPT_E_DEVICE; }
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess) {
         if (c->ev_fork) hipEventDestroy(c->ev_fork);
+        if (c->ev_join) hipEventDestroy(c->ev_join);
+        if (c->ev_fork2) hipEventDestroy(c->ev_fork2);
         if (c->side) hipStreamDestroy(c->side);
         hipStreamDestroy(c->stream);
         delete c;
@@ -45,7 +49,7 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     for (auto &kv : ctx->timers) for (auto &e : kv.second.ev) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
     if (ctx->arena) hipFree(ctx->arena);
     hipStreamSynchronize(ctx->side);
-    hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join);
+    hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join); hipEventDestroy(ctx->ev_fork2); hipEventDestroy(ctx->ev_join2);
     hipStreamDestroy(ctx->side);
     hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -50,7 +50,8 @@ int mopt_launch_project_hess(mopt_ctx *ctx, int n, int batch, const double *d_H,
                              double *d_Q, double *d_W, double *d_A);
 // variant 0: RSIRFO._project_grad_tr_rot; 1: EnhancedRSPRFO._project_grad_tr_rot (no projection below 3 atoms, QR columns
 // with |R_jj| <= 1e-10 dropped)
-int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp, int variant = 0);
+int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp, int variant = 0,
+                             bool side_stream = false);
 int mopt_launch_matvec(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_v, double *d_out);
 int mopt_launch_sym_add(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, double *d_A);
 int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);

@@ -53,18 +53,19 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
                          double *d_Hinpl, double *d_Hsym, bool warm_eigh) {
     int rc;
     const mopt::UpdateCoef *coef = nullptr;
+    rc = mopt_launch_project_grad(ctx, n, batch, wk.bg, wk.x, wk.gp, 0, /*side_stream=*/true);      // joined in front of the RFO stage
+    if (rc != MOPT_OK) return rc;
     if (any_update) {
         rc = mopt_launch_hess_update(ctx, n, batch, wk.rules, wk.do_update, any_flowchart, wk.x, wk.px, wk.g, wk.pg, wk.s, wk.y,
                                      wk.u, wk.Hy, wk.yd, wk.Av, wk.coef, wk.info, wk.H, d_Hinpl, d_Hsym, false);
         if (rc != MOPT_OK) return rc;
         coef = wk.coef;
     }
-    rc = mopt_launch_project_grad(ctx, n, batch, wk.bg, wk.x, wk.gp);
-    if (rc != MOPT_OK) return rc;
     rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A);
     if (rc != MOPT_OK) return rc;
     rc = mopt_eigh_auto(ctx, wk, n, batch, warm_eigh);
     if (rc != MOPT_OK) return rc;
+    MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));       // the projected gradient (side stream)
     rc = mopt_launch_rfo(ctx, n, batch, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, wk.gp, wk.bg, wk.be, coef,
                          wk.gt_all, wk.coefout, wk.step);
     return rc;
