@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256) k_rank1(int n, int first, const double *_
 }
 
 // grid = owned images, block 128, dynamic LDS: 2 * n doubles
-__global__ void __launch_bounds__(128) k_neb_post(int I, int N, int first, int optimize_num, int have_prev, double ratio, int fix_init,
+__global__ void __launch_bounds__(512) k_neb_post(int I, int N, int first, int optimize_num, int have_prev, double ratio, int fix_init,
                                                   int fix_end, const double *__restrict__ X, const double *__restrict__ G,
                                                   const double *__restrict__ F, const double *__restrict__ pF,
                                                   const double *__restrict__ rfo_step, double *__restrict__ rfo_delta_out,
@@ -418,7 +418,7 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
     // 4.-7. step limit, TR_calc, FIRE, blend
     {
         mopt_scope sc(ctx, "neb_post", 1);
-        hipLaunchKernelGGL(k_neb_post, dim3(count), dim3(128), (size_t)2 * n * 8, ctx->stream, I, N, first, optimize_num,
+        hipLaunchKernelGGL(k_neb_post, dim3(count), dim3(512), (size_t)2 * n * 8, ctx->stream, I, N, first, optimize_num,
                            have_prev ? 1 : 0, b->ratio, b->fix_init, b->fix_end, b->X, b->G, b->F, b->pF, wk.step, b->rfo_delta, b->newX);
     }
     MOPT_HIP_TRY(ctx, hipGetLastError());

@@ -114,7 +114,7 @@ struct mopt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;              // helper stream for work that is independent of the main chain (fork/join by events)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     std::string err;
     bool timing = false;
     std::map<std::string, mopt_timer> timers;

@@ -267,16 +267,31 @@ __global__ void __launch_bounds__(256) k_proj_grad(int n, int variant, const dou
 
 }  // namespace mopt
 
+// basis_ready: the TR/rot basis Q was already requested on the side stream (mopt_launch_trrot_basis_side); wait for it
+// in front of the first kernel that reads it
 int mopt_launch_project_hess(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, const double *d_X,
-                             double *d_Q, double *d_W, double *d_A) {
+                             double *d_Q, double *d_W, double *d_A, bool basis_ready) {
     using namespace mopt;
-    mopt_scope sc(ctx, "project", 5);
-    hipLaunchKernelGGL(k_trrot_basis, dim3(batch), dim3(256), (size_t)12 * n * sizeof(double), ctx->stream, n, d_X, d_Q);
+    mopt_scope sc(ctx, "project", basis_ready ? 4 : 5);
+    if (!basis_ready) hipLaunchKernelGGL(k_trrot_basis, dim3(batch), dim3(256), (size_t)12 * n * sizeof(double), ctx->stream, n, d_X, d_Q);
     const int T = (n + 31) / 32;
     hipLaunchKernelGGL(k_sym_add, dim3(T * T, batch), dim3(256), 0, ctx->stream, n, d_H, d_Bias, d_A);
+    if (basis_ready) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join3, 0));
     hipLaunchKernelGGL(k_proj_w, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_A, d_Q, d_W);
     hipLaunchKernelGGL(k_proj_fix, dim3(batch), dim3(256), 0, ctx->stream, n, d_Q, d_W);
     hipLaunchKernelGGL(k_proj_apply, dim3(T * T, batch), dim3(256), 0, ctx->stream, n, d_A, d_Q, d_W);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+// The basis depends on the geometry only: fork from the main stream, build it on the side stream (followed there by the
+// gradient projection, see below) and let the main stream run the Hessian update meanwhile.
+int mopt_launch_trrot_basis_side(mopt_ctx *ctx, int n, int batch, const double *d_X, double *d_Q) {
+    using namespace mopt;
+    MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork3, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork3, 0));
+    hipLaunchKernelGGL(k_trrot_basis, dim3(batch), dim3(256), (size_t)12 * n * sizeof(double), ctx->side, n, d_X, d_Q);
+    MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join3, ctx->side));
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

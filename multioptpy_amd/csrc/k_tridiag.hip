@@ -1479,15 +1479,20 @@ __global__ void __launch_bounds__(256) k_tri_clusters(int n, int batch, const do
         flgL[i] = (first || gap > 1e-3 * onenrm[i]) ? 1 : 0;
     }
     __syncthreads();
-    if (tid == 0) {
+    // stream compaction by ballots: wave 0 lists the tight cluster starts, wave 1 the loose ones (64 entries per pass)
+    const int wid = tid >> 6, lane = tid & 63;
+    if (wid < 2) {
+        const int *f = wid ? flgL : flg;
+        int *cs = wid ? cstartL : cstart;
         int nc = 0;
-        for (int j = 0; j < n; ++j) if (flg[j]) cstart[nc++] = j;
-        ncl_[b] = nc;
-    }
-    if (tid == 64) {
-        int nc = 0;
-        for (int j = 0; j < n; ++j) if (flgL[j]) cstartL[nc++] = j;
-        ncl_[batch + b] = nc;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int j = c0 + lane;
+            const bool on = (j < n) && f[j];
+            const unsigned long long m = __ballot(on);
+            if (on) cs[nc + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            nc += __popcll(m);
+        }
+        if (lane == 0) ncl_[wid * batch + b] = nc;
     }
 }
 

@@ -26,7 +26,11 @@ extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev_join2) hipEventDestroy(c->ev_join2);
+        if (c->ev_fork3) hipEventDestroy(c->ev_fork3);
         if (c->ev_fork) hipEventDestroy(c->ev_fork);
         if (c->ev_join) hipEventDestroy(c->ev_join);
         if (c->ev_fork2) hipEventDestroy(c->ev_fork2);
@@ -50,6 +54,7 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     if (ctx->arena) hipFree(ctx->arena);
     hipStreamSynchronize(ctx->side);
     hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join); hipEventDestroy(ctx->ev_fork2); hipEventDestroy(ctx->ev_join2);
+    hipEventDestroy(ctx->ev_fork3); hipEventDestroy(ctx->ev_join3);
     hipStreamDestroy(ctx->side);
     hipStreamDestroy(ctx->stream);
     delete ctx;

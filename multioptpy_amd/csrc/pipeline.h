@@ -46,8 +46,9 @@ int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules,
                             double *d_s, double *d_y, double *d_u, double *d_Hy, double *d_yd, double *d_A,
                             mopt::UpdateCoef *d_coef, double *d_info, const double *d_H, double *d_Hinpl, double *d_Hsym,
                             bool have_sy, bool guard_sy = true);
+int mopt_launch_trrot_basis_side(mopt_ctx *ctx, int n, int batch, const double *d_X, double *d_Q);
 int mopt_launch_project_hess(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, const double *d_X,
-                             double *d_Q, double *d_W, double *d_A);
+                             double *d_Q, double *d_W, double *d_A, bool basis_ready = false);
 // variant 0: RSIRFO._project_grad_tr_rot; 1: EnhancedRSPRFO._project_grad_tr_rot (no projection below 3 atoms, QR columns
 // with |R_jj| <= 1e-10 dropped)
 int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g, const double *d_X, double *d_gp, int variant = 0,

@@ -53,6 +53,8 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
                          double *d_Hinpl, double *d_Hsym, bool warm_eigh) {
     int rc;
     const mopt::UpdateCoef *coef = nullptr;
+    rc = mopt_launch_trrot_basis_side(ctx, n, batch, wk.x, wk.Q);                                    // joined in front of k_proj_w
+    if (rc != MOPT_OK) return rc;
     rc = mopt_launch_project_grad(ctx, n, batch, wk.bg, wk.x, wk.gp, 0, /*side_stream=*/true);      // joined in front of the RFO stage
     if (rc != MOPT_OK) return rc;
     if (any_update) {
@@ -61,7 +63,7 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
         if (rc != MOPT_OK) return rc;
         coef = wk.coef;
     }
-    rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A);
+    rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A, /*basis_ready=*/true);
     if (rc != MOPT_OK) return rc;
     rc = mopt_eigh_auto(ctx, wk, n, batch, warm_eigh);
     if (rc != MOPT_OK) return rc;
