@@ -63,7 +63,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
                              double *d_W, int *d_perm, int *d_info, double *d_Z2);
 // algorithm switch: 0 = block Jacobi (k_eigh.hip), 1 = tridiagonal reduction route (k_tridiag.hip); env MOPT_EIGH_ALGO overrides
-int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm);
+int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, bool preserve_A = true);
 int mopt_eigh_algo(int n);   // 1 = reduction route (k_tridiag.hip), 0 = one-sided Jacobi (k_eigh.hip)
 int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const int *d_perm, double *d_V);
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
