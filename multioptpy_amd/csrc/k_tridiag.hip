@@ -130,6 +130,9 @@ __global__ void __launch_bounds__(1024) k_tridiag(int n, int dbg, double *__rest
 // so every trailing element is read and written once per step.  Global rows are dealt to the TRI_G workgroups in chunks of
 // 8 (cyclic), which fixes the summation order independently of the batch size.
 constexpr int TRI_G = 8;
+#ifndef MOPT_P3_RW0
+#define MOPT_P3_RW0 0                        // k_tri_persist3: 1 = wave 0 owns no rows (see there)
+#endif
 constexpr int TRI_RC = 8;
 
 // state per matrix: V[n] current reflector (index = global row), PART[TRI_G][n] partial SYMV, SC[4] = {tau_k}
@@ -937,7 +940,10 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
                                                        double *__restrict__ E_, double *__restrict__ TAU_, u64 *__restrict__ XCH_,
                                                        size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof, int nmat,
                                                        int per_x, int try_local) {
-    constexpr int NW = 16, NS = 64 * CH;
+    // MOPT_P3_RW0 = 1 makes wave 0 a pure communication wave (polls, prologue, no rows), back at the exchange right behind
+    // the barrier instead of behind its own share of the main pass.  Measured on one box (n = 300, 32 matrices): 0.667 ms
+    // against 0.640 ms with rows on all 16 waves -- the continuous polling costs more than the earlier start gains.
+    constexpr int RW0 = MOPT_P3_RW0, NW = 16 - RW0, NS = 64 * CH;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_fail, s_xloc;
     long long t_poll = 0, t_pro = 0, t_main = 0, t_bar = 0, t0 = 0, t1 = 0;
@@ -989,19 +995,19 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
     if constexpr (TR > 0) {
 #pragma unroll
         for (int t = 0; t < TR; ++t) {
-            const int r = wid + NW * t;
+            const int r = (wid >= RW0) ? (wid - RW0) + NW * t : rows_cap;
             const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
             gi_t[t] = (r < r_end) ? gi : -1;
 #pragma unroll
             for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; areg[t][q] = (r < r_end && jj < n) ? A[(size_t)gi * n + jj] : 0.0; }
         }
-        if (g == 0 && wid == 0) {                            // row 0: tag 1 in buffer 1 (step k = -1)
+        if (g == 0 && wid == RW0) {                          // row 0: tag 1 in buffer 1 (step k = -1)
 #pragma unroll
             for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16(rsR, (int)(((size_t)n + jj) * 16), areg[0][q], 1u, xlocs); }
         }
     } else {
         gi_t[0] = -1;
-        for (int r = wid; r < r_end; r += NW) {
+        for (int r = (wid >= RW0) ? wid - RW0 : r_end; r < r_end; r += NW) {
             const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
 #pragma unroll
             for (int q = 0; q < CH; ++q) {
@@ -1118,7 +1124,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
         if (s_fail) return false;
         if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
         // ---- main pass: rank-2 update of the live rows with (v, w), then p_i = row_i . v' reduced inside the wave
-        {
+        if (!(RW0 && wid == 0)) {
             double wj[CH], vj[CH], zj[CH];
 #pragma unroll
             for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; wj[q] = sw[jj]; vj[q] = sv[jj]; zj[q] = svn[jj]; }
@@ -1153,7 +1159,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
                 int r_first;
                 if (own_next) r_first = ((m - g) / G) * TRI_RC + sft;
                 else r_first = (m < g) ? 0 : ((m - g + G - 1) / G) * TRI_RC;
-                for (int rr = r_first + wid; rr < r_end; rr += NW) {
+                for (int rr = (wid >= RW0) ? r_first + wid - RW0 : r_end; rr < r_end; rr += NW) {
                     const int gi = (g + (rr / TRI_RC) * G) * TRI_RC + (rr % TRI_RC);
                     const double vi = -sv[gi], wi = -sw[gi];
                     double *Ar = Aloc + rr * ns + lane;
@@ -1212,7 +1218,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
                 for (int t = 0; t < TR; ++t)
 #pragma unroll
                     for (int q = 0; q < CH; ++q)
-                        if (r == wid + NW * t && (n - 1) == lane + 64 * q) D[n - 1] = areg[t][q];
+                        if (wid >= RW0 && r == (wid - RW0) + NW * t && (n - 1) == lane + 64 * q) D[n - 1] = areg[t][q];
             } else if (tid == 0) {
                 D[n - 1] = Aloc[r * ns + (n - 1)];
             }
@@ -1389,14 +1395,19 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
         if (lane == 0) s_rot = 0;
         double cos2max = 0.0;                                // largest squared cosine between two columns met in this sweep
         __syncthreads();
+        // round-robin tournament: pair pi of round r is ((r + pi) mod (me - 1), (r - pi) mod (me - 1)), pair 0 is (me - 1, r);
+        // both residues advance by one per round (no integer division on the critical path of a round)
+        int pa = pi % (me - 1), qa = (me - 1 - pi % (me - 1)) % (me - 1);
         for (int r = 0; r < me - 1; ++r) {
             int p = -1, q = -1;
             if (pi < npair) {
                 if (pi == 0) { p = me - 1; q = r; }
-                else { p = (r + pi) % (me - 1); q = (r - pi + (me - 1)) % (me - 1); }
+                else { p = pa; q = qa; }
                 if (p >= m || q >= m) { p = -1; q = -1; }           // the bye
                 else if (p > q) { const int tt = p; p = q; q = tt; }
             }
+            pa = (pa + 1 == me - 1) ? 0 : pa + 1;
+            qa = (qa + 1 == me - 1) ? 0 : qa + 1;
             const int pc = p < 0 ? 0 : p, qc = q < 0 ? 0 : q;
             double *gp = Gs + pc * mp, *gq = Gs + qc * mp, *vp = Vs + pc * mp, *vq = Vs + qc * mp;
             double x[KP], y[KP];
@@ -2139,7 +2150,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const int ch = (n + 63) / 64;
         const int G = G2;
         int rows = rows_for(G);
-        const int tr = (rows + 15) / 16;
+        const int tr = (rows + 15 - MOPT_P3_RW0) / (16 - MOPT_P3_RW0);      // rows per row wave
         const void *fn = nullptr;
         const int cht = cht_for();                           // the CH the kernel is instantiated with
         size_t lds_use = ((size_t)rows * (((n + 63) / 64) * 64) + (size_t)5 * 64 * cht) * 8;
