@@ -94,6 +94,11 @@ struct WaveRed {
         for (int i = threadIdx.x & 63; i < m; i += WAVE) a += f(i);
         return wave_sum(a);
     }
+    template <class F> __device__ void sum2(int m, F f, double *s0, double *s1) const {      // two sums in one pass: f(i, a0, a1) adds its terms
+        double a0 = 0.0, a1 = 0.0;
+        for (int i = threadIdx.x & 63; i < m; i += WAVE) f(i, a0, a1);
+        *s0 = wave_sum(a0); *s1 = wave_sum(a1);
+    }
     template <class P> __device__ int min_index(int m, P p) const {
         int best = m;
         for (int i = threadIdx.x & 63; i < m; i += WAVE) if (p(i)) { best = i; break; }

@@ -42,7 +42,7 @@ __device__ inline bool ill_conditioned(const WaveRed &red, const double *w, int 
     return (mx / mn) > thresh;
 }
 
-// dynamic LDS: 7 * n doubles + 2 * n ints
+// dynamic LDS: 9 * n doubles + 3 * n ints
 __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_params *__restrict__ params,
                                                    mopt_rsirfo_state *__restrict__ states, const double *__restrict__ W,
                                                    const int *__restrict__ perm, const int *__restrict__ einfo,
@@ -58,7 +58,9 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     double *stp = gs + n;        // [n] step in the filtered eigenbasis
     double *best = stp + n;      // [n] scratch
     double *fac = best + n;      // [n] sign factor of the image function per sorted position (1, -1 or 0)
-    int *vidx = (int *)(fac + n);        // [n] eigenvector (Vt row) of sorted position k
+    double *cg2 = fac + n;       // [n] (g'/alpha)^2 of the current secular solve
+    double *cw = cg2 + n;        // [n] lambda'/alpha of the current secular solve
+    int *vidx = (int *)(cw + n);         // [n] eigenvector (Vt row) of sorted position k
     int *kidx = vidx + n;                // [n] sorted position k of kept entry
     const WaveRed red;
     const long long tp0 = dbg ? wall_clock64() : 0;
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     // --- RS step (rsirfo.py:924-984)
     RsResult rr;
     rr.branch = 0; rr.alpha = p.alpha0; rr.lambda_aug0 = 0.0; rr.initial_norm = 0.0; rr.secular_iters0 = 0;
-    if (m > 0) rr = rs_step(red, p, st.trust_radius, ws, gs, m, stp, best);
+    if (m > 0) rr = rs_step(red, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw);
     __syncthreads();
     if (dbg) tp3 = wall_clock64();
     // --- finite check (rsirfo.py:455-463) and steepest-descent fallback in the full eigenbasis
@@ -281,7 +283,7 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
                     double *d_coefout, double *d_step) {
     using namespace mopt;
     mopt_scope sc(ctx, "rfo", 3);
-    const size_t lds = (size_t)7 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
+    const size_t lds = (size_t)9 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
     if (!g_rfo_lds_attr_done) {
         MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
         g_rfo_lds_attr_done = 1;

@@ -307,8 +307,13 @@ MOPT_HD inline double safe_den(double d, double floor_) {
     return d;
 }
 
+// The secular function divides every term three times (g/alpha, w/alpha, g'^2/(w' - lambda)); alpha is fixed inside one
+// solve, so with scratch (cg2, cw: m doubles each, or null) the two alpha quotients are formed once per solve and every
+// evaluation is one division per term -- the same IEEE operations on the same operands, bitwise the same sums.
 template <class R>
-MOPT_HD double secular_f(const R &red, double lmd, const double *w, const double *gt, int m, double alpha) {
+MOPT_HD double secular_f(const R &red, double lmd, const double *w, const double *gt, int m, double alpha, const double *cg2 = nullptr,
+                         const double *cw = nullptr) {
+    if (cg2) return lmd + red.sum(m, [=](int i) { return cg2[i] / safe_den(cw[i] - lmd, 1e-30); });
     return lmd + red.sum(m, [=](int i) {
         double gp = gt[i] / alpha;
         return (gp * gp) / safe_den(w[i] / alpha - lmd, 1e-30);
@@ -316,7 +321,9 @@ MOPT_HD double secular_f(const R &red, double lmd, const double *w, const double
 }
 
 template <class R>
-MOPT_HD double secular_fp(const R &red, double lmd, const double *w, const double *gt, int m, double alpha) {
+MOPT_HD double secular_fp(const R &red, double lmd, const double *w, const double *gt, int m, double alpha, const double *cg2 = nullptr,
+                          const double *cw = nullptr) {
+    if (cg2) return 1.0 + red.sum(m, [=](int i) { double dd = safe_den(cw[i] - lmd, 1e-30); return cg2[i] / (dd * dd); });
     return 1.0 + red.sum(m, [=](int i) {
         double gp = gt[i] / alpha;
         double dd = safe_den(w[i] / alpha - lmd, 1e-30);
@@ -326,20 +333,27 @@ MOPT_HD double secular_fp(const R &red, double lmd, const double *w, const doubl
 
 // _solve_secular_more_sorensen + _solve_secular_safeguarded (rsirfo.py:1505-1575, 1374-1503)
 template <class R>
-MOPT_HD double solve_secular(const R &red, const double *w, const double *gt, int m, double alpha, int *iters) {
+MOPT_HD double solve_secular(const R &red, const double *w, const double *gt, int m, double alpha, int *iters, double *cg2 = nullptr,
+                             double *cw = nullptr) {
     if (iters) *iters = 0;
-    double gnorm_sq = red.sum(m, [=](int i) { double gp = gt[i] / alpha; return gp * gp; });
-    int first = red.min_index(m, [=](int i) { double gp = gt[i] / alpha; return gp * gp > 1e-20; });
+    if (cg2) {
+        red.sync();                                             // (readers of the previous solve are done)
+        red.for_each(m, [=](int i) { double gp = gt[i] / alpha; cg2[i] = gp * gp; cw[i] = w[i] / alpha; });
+        red.sync();
+    }
+    double gnorm_sq = cg2 ? red.sum(m, [=](int i) { return cg2[i]; }) : red.sum(m, [=](int i) { double gp = gt[i] / alpha; return gp * gp; });
+    int first = cg2 ? red.min_index(m, [=](int i) { return cg2[i] > 1e-20; })
+                    : red.min_index(m, [=](int i) { double gp = gt[i] / alpha; return gp * gp > 1e-20; });
     if (first >= m) return w[0] / alpha;                       // hard case
     double pole = w[first] / alpha;
     double guess = 0.5 * (pole - sqrt(dmax(0.0, pole * pole + 4.0 * gnorm_sq)));
     double b = pole, a = guess;
-    double fa = secular_f(red, a, w, gt, m, alpha);
+    double fa = secular_f(red, a, w, gt, m, alpha, cg2, cw);
     double gnorm = sqrt(gnorm_sq);
     int limit = 10;
     while (fa > 0.0 && limit > 0) {
         a = a - dmax(dmax(gnorm, fabs(a) * 0.1), 1e-8);
-        fa = secular_f(red, a, w, gt, m, alpha);
+        fa = secular_f(red, a, w, gt, m, alpha, cg2, cw);
         --limit;
     }
     if (fa > 0.0) return guess;
@@ -347,9 +361,14 @@ MOPT_HD double solve_secular(const R &red, const double *w, const double *gt, in
     if (lk <= a || lk >= b) lk = (a + b) / 2.0;
     const double tol = 1e-10 * fabs(pole) + 1e-12;
     for (int it = 0; it < 250; ++it) {
-        double fl = secular_f(red, lk, w, gt, m, alpha);
+        double fl, fpl = 0.0;
+        if (cg2) {                                             // f and f' in one pass over the terms (same operations, two sums)
+            double s0, s1;
+            red.sum2(m, [=](int i, double &a0, double &a1) { double dd = safe_den(cw[i] - lk, 1e-30); a0 += cg2[i] / dd; a1 += cg2[i] / (dd * dd); }, &s0, &s1);
+            fl = lk + s0; fpl = 1.0 + s1;
+        } else fl = secular_f(red, lk, w, gt, m, alpha, cg2, cw);
         if (fabs(fl) < tol) { if (iters) *iters = it + 1; return lk; }
-        double fpl = secular_fp(red, lk, w, gt, m, alpha);
+        if (!cg2) fpl = secular_fp(red, lk, w, gt, m, alpha, cg2, cw);
         double dn = (fabs(fpl) > 1e-20) ? -fl / fpl : 0.0;
         double ln = lk + dn;
         double lb = (a + b) / 2.0;
@@ -365,8 +384,8 @@ MOPT_HD double solve_secular(const R &red, const double *w, const double *gt, in
 // solve_rfo (rsirfo.py:1688-1715): writes step[0..m), returns ||step||^2 via *norm2; returns lambda_aug
 template <class R>
 MOPT_HD double solve_rfo(const R &red, const double *w, const double *gt, int m, double alpha, double *step,
-                         double *norm2, int *iters) {
-    double lam = solve_secular(red, w, gt, m, alpha, iters);
+                         double *norm2, int *iters, double *cg2 = nullptr, double *cw = nullptr) {
+    double lam = solve_secular(red, w, gt, m, alpha, iters, cg2, cw);
     red.for_each(m, [=](int i) {
         double den = safe_den(w[i] / alpha - lam, 1e-20);
         step[i] = -(gt[i] / alpha) / den;
@@ -420,12 +439,12 @@ struct RsResult {
 // w, gt: the m kept eigenvalues / transformed gradient; step: output (m); best: scratch (m).
 template <class R>
 MOPT_HD RsResult rs_step(const R &red, const mopt_rsirfo_params &p, double trust_radius, const double *w,
-                         const double *gt, int m, double *step, double *best) {
+                         const double *gt, int m, double *step, double *best, double *cg2 = nullptr, double *cw = nullptr) {
     RsResult rr;
     rr.branch = 0; rr.alpha = p.alpha0; rr.secular_iters0 = 0;
     double n2;
     int its = 0;
-    rr.lambda_aug0 = solve_rfo(red, w, gt, m, p.alpha0, step, &n2, &its);
+    rr.lambda_aug0 = solve_rfo(red, w, gt, m, p.alpha0, step, &n2, &its, cg2, cw);
     rr.secular_iters0 = its;
     rr.initial_norm = sqrt(n2);
     const double R_ = trust_radius;
@@ -435,23 +454,23 @@ MOPT_HD RsResult rs_step(const R &red, const mopt_rsirfo_params &p, double trust
     double alpha = p.alpha0;
     {
         double n2lo, n2hi;
-        solve_rfo(red, w, gt, m, 1e-6, step, &n2lo, nullptr);
+        solve_rfo(red, w, gt, m, 1e-6, step, &n2lo, nullptr, cg2, cw);
         double nlo = sqrt(n2lo);
         double obj_lo = nlo * nlo - R_ * R_;
-        solve_rfo(red, w, gt, m, p.alpha_max, step, &n2hi, nullptr);
+        solve_rfo(red, w, gt, m, p.alpha_max, step, &n2hi, nullptr, cg2, cw);
         double nhi = sqrt(n2hi);
         double obj_hi = nhi * nhi - R_ * R_;
         if (obj_lo * obj_hi < 0.0) {
             double root = 0.0;
             auto obj = [&](double a) {
                 double q;
-                solve_rfo(red, w, gt, m, a, step, &q, nullptr);
+                solve_rfo(red, w, gt, m, a, step, &q, nullptr, cg2, cw);
                 return q - R_ * R_;
             };
             int ok = brentq(obj, 1e-6, p.alpha_max, 1e-6, 1e-6, 50, &root);
             if (ok == 0) {
                 double q;
-                solve_rfo(red, w, gt, m, root, step, &q, nullptr);
+                solve_rfo(red, w, gt, m, root, step, &q, nullptr, cg2, cw);
                 double nrm = sqrt(q);
                 if (fabs(nrm - R_) < p.step_norm_tolerance) { rr.branch = 1; rr.alpha = root; return rr; }
                 alpha = root;
@@ -473,7 +492,7 @@ MOPT_HD RsResult rs_step(const R &red, const mopt_rsirfo_params &p, double trust
     bool broke = false;
     for (int mu = 0; mu < max_mc; ++mu) {
         double q;
-        double lam = solve_rfo(red, w, gt, m, alpha, step, &q, nullptr);
+        double lam = solve_rfo(red, w, gt, m, alpha, step, &q, nullptr, cg2, cw);
         double nrm = sqrt(q);
         double diff = fabs(nrm - R_);
         if (diff < best_diff) {

@@ -9,6 +9,7 @@
 namespace {
 struct SerialRed {
     template <class F> double sum(int m, F f) const { double a = 0.0; for (int i = 0; i < m; ++i) a += f(i); return a; }
+    template <class F> void sum2(int m, F f, double *s0, double *s1) const { double a0 = 0.0, a1 = 0.0; for (int i = 0; i < m; ++i) f(i, a0, a1); *s0 = a0; *s1 = a1; }
     template <class P> int min_index(int m, P p) const { for (int i = 0; i < m; ++i) if (p(i)) return i; return m; }
     template <class F> void for_each(int m, F f) const { for (int i = 0; i < m; ++i) f(i); }
     void sync() const {}
@@ -33,9 +34,9 @@ int sim_rule_is_block(int rule) { return mopt::rule_is_block(rule); }
 
 int sim_rs_step(const mopt_rsirfo_params *p, double trust_radius, const double *w, const double *gt, int m,
                 double *step, double *res5) {
-    std::vector<double> best(m > 0 ? m : 1);
+    std::vector<double> best(m > 0 ? m : 1), cg2(m > 0 ? m : 1), cw(m > 0 ? m : 1);      // scratch as in k_rfo_scalar (cached alpha quotients)
     SerialRed red;
-    mopt::RsResult r = mopt::rs_step(red, *p, trust_radius, w, gt, m, step, best.data());
+    mopt::RsResult r = mopt::rs_step(red, *p, trust_radius, w, gt, m, step, best.data(), cg2.data(), cw.data());
     res5[0] = r.branch; res5[1] = r.alpha; res5[2] = r.lambda_aug0; res5[3] = r.initial_norm; res5[4] = r.secular_iters0;
     return 0;
 }
