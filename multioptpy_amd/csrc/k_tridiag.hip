@@ -130,9 +130,15 @@ __global__ void __launch_bounds__(1024) k_tridiag(int n, int dbg, double *__rest
 // so every trailing element is read and written once per step.  Global rows are dealt to the TRI_G workgroups in chunks of
 // 8 (cyclic), which fixes the summation order independently of the batch size.
 constexpr int TRI_G = 8;
+#ifndef MOPT_P3_PREDELAY
+#define MOPT_P3_PREDELAY 0                   // k_tri_persist3: s_sleep units (64 clocks) in front of the first poll pass of a step
+// (measured, n = 300, 32 matrices, one box: 0 / 1 / 2 / 4 / 8 units -> 0.640 / 0.641 / 0.642 / 0.653 / 0.674 ms: the first pass does
+// not "just miss" the partner data, a delay only adds to the step)
+#endif
 #ifndef MOPT_P3_RW0
 #define MOPT_P3_RW0 0                        // k_tri_persist3: 1 = wave 0 owns no rows (see there)
 #endif
+constexpr double TRI_TIGHT = 1e-7;
 constexpr int TRI_RC = 8;
 
 // state per matrix: V[n] current reflector (index = global row), PART[TRI_G][n] partial SYMV, SC[4] = {tau_k}
@@ -1039,6 +1045,9 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
             if (prof) t0 = wall_clock64();
             u32x4 xp[CH], xr[CH];
             unsigned spins = 0;
+#if MOPT_P3_PREDELAY > 0
+            __builtin_amdgcn_s_sleep(MOPT_P3_PREDELAY);      // see the note at the definition
+#endif
             for (;;) {
                 asm volatile("" ::: "memory");               // buffer loads are ordinary loads to the compiler: re-issue every pass
 #pragma unroll
@@ -1459,6 +1468,25 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
     }
 }
 
+// Membership of vector j in a loose (1e-3) cluster that spans more than one tight cluster inside a block solved by inverse
+// iteration: such clusters are orthogonalised by the Loewdin passes.  Returns the cluster [j0, j1) and the block [s, t).
+__device__ __forceinline__ bool loose_cluster_of(int n, int batch, int b, int j, const int *bstart_, const int *bend_, const int *cstart_,
+                                                 const int *ncl_, const double *WT, const double *onenrm, int small_max, int &j0, int &j1,
+                                                 int &s, int &t) {
+    const int *cstartL = cstart_ + (size_t)(batch + b) * n;
+    const int ncL = ncl_[batch + b];
+    s = bstart_[(size_t)b * n + j]; t = bend_[(size_t)b * n + j];
+    const int m = t - s;
+    if (m < 2 || m <= small_max) return false;
+    int lo = 0, hi = ncL - 1;                                   // last loose cluster start <= j
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cstartL[mid] <= j) lo = mid; else hi = mid - 1; }
+    j0 = cstartL[lo];
+    j1 = (lo + 1 < ncL && cstartL[lo + 1] < t) ? cstartL[lo + 1] : t;
+    if (j1 - j0 < 2) return false;
+    for (int i = j0 + 1; i < j1; ++i) if (fabs(WT[i] - WT[i - 1]) > TRI_TIGHT * onenrm[i]) return true;     // more than one tight cluster
+    return false;
+}
+
 // After the bisection: publish the split off-diagonal and build TWO cluster tables.  One workgroup per matrix.
 //   tight clusters (gap <= TRI_TIGHT ||T_block||_1): eigenvalues that inverse iteration cannot separate on its own; they are
 //       processed in sequence by one wave with perturbed shifts and re-orthogonalisation in every iteration (dstein);
@@ -1468,10 +1496,10 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
 //       Gram-Schmidt only removes that residue.  dstein's strictly sequential treatment of a 1e-3 cluster made one wave walk
 //       >100 vectors of a molecular Hessian's dense low end (122 ms for one 300 x 300 matrix).
 // Tables: tight at cstart_[b n ..], ncl_[b]; loose at cstart_[(batch + b) n ..], ncl_[batch + b].   dynamic LDS: 2 n ints
-constexpr double TRI_TIGHT = 1e-7;
 __global__ void __launch_bounds__(256) k_tri_clusters(int n, int batch, const double *__restrict__ D_, double *__restrict__ E_,
                                                       const double *__restrict__ WT_, const int *__restrict__ bstart_,
-                                                      const double *__restrict__ onenrm_, int *__restrict__ cstart_, int *__restrict__ ncl_) {
+                                                      const double *__restrict__ onenrm_, int *__restrict__ cstart_, int *__restrict__ ncl_,
+                                                      const int *__restrict__ bend_, int small_max, int *__restrict__ wl_, int *__restrict__ wcnt_) {
     extern __shared__ __attribute__((aligned(16))) int flg[];
     int *flgL = flg + n;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1505,6 +1533,22 @@ __global__ void __launch_bounds__(256) k_tri_clusters(int n, int batch, const do
         }
         if (lane == 0) ncl_[wid * batch + b] = nc;
     }
+    // work list of the Loewdin passes: the vectors of this matrix that sit in a loose cluster needing orthogonalisation
+    // (usually none on the NEB path, whose blocks are small and solved whole: the passes then cost two empty launches of a
+    // few hundred workgroups instead of four launches of n * batch).  wl_[b][.] and wcnt_[2 b] are scratch of k_tri_sort's outputs.
+    __syncthreads();
+    if (wid == 0) {
+        int nc = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int j = c0 + lane;
+            int j0, j1, s_, t_;
+            const bool on = (j < n) && loose_cluster_of(n, batch, b, j, bstart_, bend_, cstart_, ncl_, WT, onenrm, small_max, j0, j1, s_, t_);
+            const unsigned long long m = __ballot(on);
+            if (on) wl_[(size_t)b * n + nc + __popcll(m & ((1ull << lane) - 1ull))] = j;
+            nc += __popcll(m);
+        }
+        if (lane == 0) wcnt_[2 * b] = nc;
+    }
 }
 
 // Orthogonalise the vectors of every loose cluster that spans more than one tight cluster.  The independently iterated
@@ -1512,31 +1556,18 @@ __global__ void __launch_bounds__(256) k_tri_clusters(int n, int batch, const do
 // overlaps of order |G - I|^2 < 1e-15; it is applied twice.  No vector waits for another: workgroup j forms row j of G (its
 // vector against the whole cluster, one dot per wave at a time) and then its new vector, written to the scratch copy Z2;
 // k_tri_lowdin_copy moves the rows back.  grid (n, batch), one workgroup per eigenvector.   dynamic LDS: n doubles
-__device__ __forceinline__ bool loose_cluster_of(int n, int batch, int b, int j, const int *bstart_, const int *bend_, const int *cstart_,
-                                                 const int *ncl_, const double *WT, const double *onenrm, int small_max, int &j0, int &j1,
-                                                 int &s, int &t) {
-    const int *cstartL = cstart_ + (size_t)(batch + b) * n;
-    const int ncL = ncl_[batch + b];
-    s = bstart_[(size_t)b * n + j]; t = bend_[(size_t)b * n + j];
-    const int m = t - s;
-    if (m < 2 || m <= small_max) return false;
-    int lo = 0, hi = ncL - 1;                                   // last loose cluster start <= j
-    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cstartL[mid] <= j) lo = mid; else hi = mid - 1; }
-    j0 = cstartL[lo];
-    j1 = (lo + 1 < ncL && cstartL[lo + 1] < t) ? cstartL[lo + 1] : t;
-    if (j1 - j0 < 2) return false;
-    for (int i = j0 + 1; i < j1; ++i) if (fabs(WT[i] - WT[i - 1]) > TRI_TIGHT * onenrm[i]) return true;     // more than one tight cluster
-    return false;
-}
 
 __global__ void __launch_bounds__(1024) k_tri_lowdin(int n, int batch, const int *__restrict__ bstart_, const int *__restrict__ bend_,
                                                     const int *__restrict__ cstart_, const int *__restrict__ ncl_, const double *__restrict__ WT_,
                                                     const double *__restrict__ onenrm_, const double *__restrict__ Zt_, double *__restrict__ Z2_,
-                                                    int small_max) {
+                                                    int small_max, const int *__restrict__ wl_, const int *__restrict__ wcnt_) {
     extern __shared__ __attribute__((aligned(16))) double grow[];
-    const int b = blockIdx.y, j = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int cnt = wcnt_[2 * b];
+    for (int w = blockIdx.x; w < cnt; w += gridDim.x) {
+    const int j = wl_[(size_t)b * n + w];
     int j0, j1, s, t;
-    if (!loose_cluster_of(n, batch, b, j, bstart_, bend_, cstart_, ncl_, WT_ + (size_t)b * n, onenrm_ + (size_t)b * n, small_max, j0, j1, s, t)) return;
+    if (!loose_cluster_of(n, batch, b, j, bstart_, bend_, cstart_, ncl_, WT_ + (size_t)b * n, onenrm_ + (size_t)b * n, small_max, j0, j1, s, t)) continue;
     const int m = t - s;
     const double *Z = Zt_ + (size_t)b * n * n + s;
     const double *zj = Z + (size_t)j * n;
@@ -1555,17 +1586,23 @@ __global__ void __launch_bounds__(1024) k_tri_lowdin(int n, int batch, const int
         for (int i = j0; i < j1; ++i) acc -= 0.5 * grow[i - j0] * Z[(size_t)i * n + k];
         out[k] = acc;
     }
+    __syncthreads();                                         // grow[] is reused by the next work item
+    }
 }
 
 __global__ void __launch_bounds__(256) k_tri_lowdin_copy(int n, int batch, const int *__restrict__ bstart_, const int *__restrict__ bend_,
                                                          const int *__restrict__ cstart_, const int *__restrict__ ncl_, const double *__restrict__ WT_,
                                                          const double *__restrict__ onenrm_, double *__restrict__ Zt_, const double *__restrict__ Z2_,
-                                                         int small_max) {
-    const int b = blockIdx.y, j = blockIdx.x;
-    int j0, j1, s, t;
-    if (!loose_cluster_of(n, batch, b, j, bstart_, bend_, cstart_, ncl_, WT_ + (size_t)b * n, onenrm_ + (size_t)b * n, small_max, j0, j1, s, t)) return;
-    const size_t off = (size_t)b * n * n + (size_t)j * n + s;
-    for (int k = threadIdx.x; k < t - s; k += blockDim.x) Zt_[off + k] = Z2_[off + k];
+                                                         int small_max, const int *__restrict__ wl_, const int *__restrict__ wcnt_) {
+    const int b = blockIdx.y;
+    const int cnt = wcnt_[2 * b];
+    for (int w = blockIdx.x; w < cnt; w += gridDim.x) {
+        const int j = wl_[(size_t)b * n + w];
+        int j0, j1, s, t;
+        if (!loose_cluster_of(n, batch, b, j, bstart_, bend_, cstart_, ncl_, WT_ + (size_t)b * n, onenrm_ + (size_t)b * n, small_max, j0, j1, s, t)) continue;
+        const size_t off = (size_t)b * n * n + (size_t)j * n + s;
+        for (int k = threadIdx.x; k < t - s; k += blockDim.x) Zt_[off + k] = Z2_[off + k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2329,7 +2366,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                            ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm, small_max);
         if (small_max > 0)
             hipLaunchKernelGGL(k_tri_small, dim3(n, batch), dim3(64), 0, ctx->stream, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
-        hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)2 * n * 4, ctx->stream, n, batch, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl);
+        hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)2 * n * 4, ctx->stream, n, batch, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl,
+                           (const int *)d_bend, small_max, d_perm, d_info);
     }
     {
         mopt_scope sc(ctx, "eigh_invit", 1);
@@ -2339,11 +2377,14 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const int extra = getenv("MOPT_INVIT_EXTRA") ? atoi(getenv("MOPT_INVIT_EXTRA")) : 1;
         hipLaunchKernelGGL(k_tri_invit, dim3(n, batch), dim3(64), perwave, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_cstart,
                            d_ncl, d_onenrm, d_Vt, d_fail, extra, getenv("MOPT_INVIT_DBG") ? 1 : 0, small_max);
+        // work-list driven (k_tri_clusters): lw workgroups per matrix walk its list
+        int lw = 2048 / batch;
+        lw = lw < 8 ? 8 : (lw > n ? n : lw);
         for (int pass = 0; pass < 2; ++pass) {
-            hipLaunchKernelGGL(k_tri_lowdin, dim3(n, batch), dim3(n > 256 ? 1024 : 256), (size_t)n * 8, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT,
-                               d_onenrm, d_Vt, d_Z2, small_max);
-            hipLaunchKernelGGL(k_tri_lowdin_copy, dim3(n, batch), dim3(256), 0, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT, d_onenrm,
-                               d_Vt, d_Z2, small_max);
+            hipLaunchKernelGGL(k_tri_lowdin, dim3(lw, batch), dim3(n > 256 ? 1024 : 256), (size_t)n * 8, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT,
+                               d_onenrm, d_Vt, d_Z2, small_max, (const int *)d_perm, (const int *)d_info);
+            hipLaunchKernelGGL(k_tri_lowdin_copy, dim3(lw, batch), dim3(256), 0, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT, d_onenrm,
+                               d_Vt, d_Z2, small_max, (const int *)d_perm, (const int *)d_info);
         }
     }
     if (bt_mfma) {
