@@ -2163,7 +2163,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     // G = 8 / 16 / 32 -> poll 1.9 / 2.8 / 4.5 us per step against 1.9 / 1.5 / 1.3 us for LDS pass + barrier.  MOPT_TRI_GMAX
     // (default 8) raises the cap for experiments.
     {
-        const int gmax = getenv("MOPT_TRI_GMAX") ? atoi(getenv("MOPT_TRI_GMAX")) : 8;
+        // k_tri_persist3 exchanges n values per step whatever G is, so idle CUs do pay there: n = 300, 4 or 8 matrices (a band
+        // sharded over 8 or 4 GPUs): G = 8 / 16 / 32 -> 0.614 / 0.602 / 0.555 ms.
+        const int gmax = getenv("MOPT_TRI_GMAX") ? atoi(getenv("MOPT_TRI_GMAX")) : (want3 ? ctx->num_cu / 8 : 8);
         while (!g_forced && 2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
     }
     // (the members of a matrix are placed on ONE XCD: a group cannot be larger than its num_cu / 8 compute units)
