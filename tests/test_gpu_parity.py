@@ -69,7 +69,7 @@ def test_projections_vs_reference(ops):
         assert np.abs(gp - z[name + "_gp"]).max() < 1e-11, name
 
 
-@pytest.mark.parametrize("n", [3, 21, 66, 150, 300])
+@pytest.mark.parametrize("n", [3, 21, 45, 66, 150, 300, 337, 384, 450])      # 337/384: last register-resident MFMA back-transformation sizes, 450: VALU form, LDS rows
 def test_eigh_random(ops, n):
     rng = np.random.default_rng(n)
     A = rng.normal(size=(n, n))
@@ -339,7 +339,8 @@ def test_rsprfo_traces_vs_reference():
     print("RSPRFO worst step deviation from the reference:", worst)
 
 
-@pytest.mark.parametrize("algo", ["tridiag", "jacobi", "tridiag-stepwise", "tridiag-persistent", "tridiag-nosmall"])
+@pytest.mark.parametrize("algo", ["tridiag", "jacobi", "tridiag-stepwise", "tridiag-persistent", "tridiag-nosmall", "tridiag-persist2",
+                                  "tridiag-valubacktrans", "tridiag-group8"])
 def test_eigh_forced_route(ops, algo):
     """Both eigen-solvers forced for every size (MOPT_EIGH_ALGO): random, degenerate, clustered and LJ matrices.
     (By default the reduction route runs from n = 32 on and the Jacobi sweeps below.)"""
@@ -385,7 +386,8 @@ for b in range(40):
 sys.exit(bad)
 '''
     extra = {"tridiag-stepwise": {"MOPT_TRI_NOPERSIST": "1"}, "tridiag-persistent": {"MOPT_TRI_FORCEPERSIST": "1"},
-             "tridiag-nosmall": {"MOPT_TRI_SMALL": "0"}}.get(algo, {})
+             "tridiag-nosmall": {"MOPT_TRI_SMALL": "0"}, "tridiag-persist2": {"MOPT_TRI_P3": "0"},
+             "tridiag-valubacktrans": {"MOPT_BT_MFMA": "0"}, "tridiag-group8": {"MOPT_TRI_GMAX": "8"}}.get(algo, {})
     env = dict(os.environ, MOPT_EIGH_ALGO=algo.split("-")[0], **extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     print(r.stdout)
