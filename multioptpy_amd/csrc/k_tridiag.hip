@@ -952,6 +952,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
     constexpr int RW0 = MOPT_P3_RW0, NW = 16 - RW0, NS = 64 * CH;
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_fail, s_xloc;
+    __shared__ double s_mail[8];                             // [2][4] D, E, TAU of a step on their way to the storing wave
     long long t_poll = 0, t_pro = 0, t_main = 0, t_bar = 0, t0 = 0, t1 = 0;
     const long long c_start = prof ? clock64() : 0, w_start = prof ? wall_clock64() : 0;
     double *vb = sm, *wb = sm + 3 * NS;                     // v[3][NS], w[2][NS]
@@ -1119,11 +1120,12 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
                 const int jj = lane + 64 * q;
                 const double vn = rq[q] * scal;
                 svn[jj] = vn;
-                if (g == 0 && jj >= lo + 2 && jj < n) A[(size_t)lo * n + jj] = vn;       // reflector of step k+1, dsytrd layout (row lo)
             }
             if (lane == 0) {
                 svn[lo + 1] = 1.0;                           // (behind the vector stores: LDS operations of a wave stay in order)
-                if (g == 0) { D[lo] = diag; E[lo] = betan; TAU[lo] = taun; if (lo == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; } }
+                // D, E, TAU of this step: left in LDS for the last wave, which stores them (and the reflector) behind its rows --
+                // workgroup 0 is on the critical path of every step and its wave 0 should carry nothing the others do not
+                if (g == 0) { double *mb = s_mail + 4 * (nxt & 1); mb[0] = diag; mb[1] = betan; mb[2] = taun; }
             }
             tau = taun;
             }
@@ -1192,6 +1194,15 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
                     d0 = wave_sum63(d0);
                     if (lane == 63) put16(rsP, (nxt * n + gi) * 16, d0, tag + 1u, xlocs);
                 }
+            }
+        }
+        if (g == 0 && wid == 15) {                           // results of the step for the host side: reflector (row lo, dsytrd layout), D, E, TAU
+#pragma unroll
+            for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj >= lo + 2 && jj < n) A[(size_t)lo * n + jj] = svn[jj]; }
+            if (lane == 0) {
+                const double *mb = s_mail + 4 * (nxt & 1);
+                D[lo] = mb[0]; E[lo] = mb[1]; TAU[lo] = mb[2];
+                if (lo == n - 2) { TAU[n - 1] = 0.0; E[n - 1] = 0.0; }
             }
         }
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
