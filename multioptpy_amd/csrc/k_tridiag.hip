@@ -297,6 +297,14 @@ __device__ __forceinline__ void ll_put_s(u64 *p, double v, unsigned tag, bool lo
 }
 // both tagged words of a value in ONE 16-byte store (aux 1 = sc0: XCD-local, aux 16 = sc1: write-through); every 8-byte half is
 // still self-validating, a reader that sees only one of them reads again
+template <bool LOCAL>
+__device__ __forceinline__ void put16c(__amdgpu_buffer_rsrc_t rs, int byte_off, double v, unsigned tag) {      // scope fixed at compile time
+    const u64 bits = (u64)__double_as_longlong(v);
+    u32x4 w;
+    w[0] = (unsigned)bits; w[1] = tag; w[2] = (unsigned)(bits >> 32); w[3] = tag;
+    if (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 1);
+    else __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 16);
+}
 __device__ __forceinline__ void put16(__amdgpu_buffer_rsrc_t rs, int byte_off, double v, unsigned tag, bool local) {
     const u64 bits = (u64)__double_as_longlong(v);
     u32x4 w;
@@ -1155,13 +1163,20 @@ __global__ void __launch_bounds__(1024) k_tri_persist3(int n, int G, int rows_ca
                         }
 #endif
                         if (gi == lo + 1) {                                             // the next pivot row: publish it
+                            // (one scope branch for the block, all columns < n: dead ones are never read -- this wave's p_i
+                            // is what the other members wait for next)
+                            if (xlocs) {
 #pragma unroll
-                            for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u, xlocs); }
+                                for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16c<true>(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u); }
+                            } else {
+#pragma unroll
+                                for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16c<false>(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u); }
+                            }
                         }
 #ifndef MOPT_P3_ABL_NORED
                         d0 = wave_sum63(d0);                                            // total in lane 63
 #endif
-                        if (lane == 63) put16(rsP, (nxt * n + gi) * 16, d0, tag + 1u, xlocs);
+                        if (lane == 63) { if (xlocs) put16c<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u); else put16c<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u); }
                     }
                 }
             } else {
