@@ -2037,7 +2037,7 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
                                                             double *__restrict__ Zt_, const int *__restrict__ bend_) {
     constexpr int LEN = 16 * NT;                                           // padded vector length
     constexpr int LDV = LEN + ((2 - LEN % 32 + 32) % 32);                   // = 2 mod 32: the 16 x 2 operand reads of step 1 hit 32 different bank pairs
-    constexpr int NTHR = 64 * WPW, NLD = (16 * LEN + NTHR - 1) / NTHR, NTL = 256 / NTHR;      // staging loads per thread: reflectors, T
+    constexpr int NTHR = 64 * WPW, NTL = 256 / NTHR;      // T entries per thread
     typedef double d4 __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *Vs = sm;                                                        // [16][LDV]
@@ -2059,25 +2059,36 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
         const int kf = tmax - 2 < 0 ? 0 : tmax - 2;
         beta_first = (kf / 16 < NB - 1) ? kf / 16 : NB - 1;
     }
-    auto fetch = [&](int beta, double (&pre)[NLD], double (&pt)[NTL]) {
+    // Staging map (WPW = 4: 256 threads): thread t carries row c = t / 16 of the block and the columns t % 16 + 16 m, one per
+    // 16-column tile m -- 128-byte row segments, addresses that differ by constants, and tiles below the block's first
+    // reflector (structural zeros, never read) are not touched at all.
+    static_assert(WPW == 4, "staging map assumes 256 threads");
+    const int sc = tid >> 4, si = tid & 15;
+    auto fetch = [&](auto bc, double (&pre)[NT], double (&pt)[NTL]) {
+        constexpr int BETA = decltype(bc)::value;
+        if constexpr (BETA >= 0) {
+            const int k = 16 * BETA + sc;
+            const double *row = A + (size_t)(k <= n - 3 ? k : 0) * n;
 #pragma unroll
-        for (int m = 0; m < NLD; ++m) {
-            const int e = tid + NTHR * m, c = e / LEN, i = e - c * LEN, k = 16 * beta + c;
-            double v = 0.0;
-            if (beta >= 0 && c < 16 && k <= n - 3) { if (i == k + 1) v = 1.0; else if (i > k + 1 && i < n) v = A[(size_t)k * n + i]; }
-            pre[m] = v;
+            for (int m = (BETA > 0 ? BETA : 0); m < NT; ++m) {
+                const int i = si + 16 * m;
+                const double a = row[i < n ? i : n - 1];
+                pre[m] = (k <= n - 3 && i > k + 1 && i < n) ? a : ((k <= n - 3 && i == k + 1) ? 1.0 : 0.0);
+            }
+#pragma unroll
+            for (int m = 0; m < NTL; ++m) pt[m] = Tg[(size_t)BETA * 256 + tid + NTHR * m];
         }
-#pragma unroll
-        for (int m = 0; m < NTL; ++m) pt[m] = (beta >= 0) ? Tg[(size_t)beta * 256 + tid + NTHR * m] : 0.0;
     };
-    auto stage = [&](const double (&pre)[NLD], const double (&pt)[NTL]) {
+    auto stage = [&](auto bc, const double (&pre)[NT], const double (&pt)[NTL]) {
+        constexpr int BETA = decltype(bc)::value;
 #pragma unroll
-        for (int m = 0; m < NLD; ++m) { const int e = tid + NTHR * m, c = e / LEN, i = e - c * LEN; if (c < 16) Vs[c * LDV + i] = pre[m]; }
+        for (int m = (BETA > 0 ? BETA : 0); m < NT; ++m) Vs[sc * LDV + si + 16 * m] = pre[m];
 #pragma unroll
         for (int m = 0; m < NTL; ++m) { const int e = tid + NTHR * m; Ts[(e >> 4) * 17 + (e & 15)] = pt[m]; }
     };
-    double pre[NLD], pt[NTL];
-    fetch(beta_first, pre, pt);
+    double pre[NT], pt[NTL];
+    // the first block to run is found at run time: its fetch is the one non-overlapped load of the sweep
+    static_for_desc(std::make_integer_sequence<int, NT>{}, [&](auto bc) { if (decltype(bc)::value == beta_first) fetch(bc, pre, pt); });
     // The sweep over the blocks is unrolled at compile time (block BETA touches components >= 16 BETA + 1 only, i.e. the
     // 16-row tiles tt >= BETA: half of the MFMAs of the rectangular form act on structural zeros), so every index into z
     // is static; blocks above beta_first are skipped by a uniform test.
@@ -2085,9 +2096,9 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
         constexpr int BETA = decltype(bc)::value;
         if (BETA <= beta_first) {
             __syncthreads();                                                // the previous block's operand reads are done
-            stage(pre, pt);
+            stage(bc, pre, pt);
             __syncthreads();
-            fetch(BETA - 1, pre, pt);                                       // in flight during the arithmetic below
+            fetch(std::integral_constant<int, BETA - 1>{}, pre, pt);       // in flight during the arithmetic below
             // 1. W^T = V^T Z^T   (two accumulators: the MFMAs of one chain depend on each other)
             // (the LDS operands are requested one group of four MFMAs ahead: a read issued right in front of its MFMA leaves
             // the matrix pipe idle for the LDS latency)
