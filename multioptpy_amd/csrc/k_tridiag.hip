@@ -2103,20 +2103,26 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
             // (the LDS operands are requested one group of four MFMAs ahead: a read issued right in front of its MFMA leaves
             // the matrix pipe idle for the LDS latency)
             d4 w0 = {0.0, 0.0, 0.0, 0.0}, w1 = {0.0, 0.0, 0.0, 0.0};
+#ifdef MOPT_BT_ABL_NOLDSOP
+            const double *va = Vs + li, *vb = Vs + lh;       // (timing ablation: every operand read hits the same few words)
+#define BT_IDX(x) 0
+#else
             const double *va = Vs + li * LDV + lh;
             const double *vb = Vs + lh * LDV + li;
+#define BT_IDX(x) (x)
+#endif
             double tq[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) tq[m] = Ts[li * 17 + 4 * m + lh];
             {
                 double ac[4], an[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) ac[u] = va[4 * (4 * BETA + u)];
+                for (int u = 0; u < 4; ++u) ac[u] = va[BT_IDX(4 * (4 * BETA + u))];
 #pragma unroll
                 for (int tt = BETA; tt < NT; ++tt) {
                     if (tt + 1 < NT) {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) an[u] = va[4 * (4 * (tt + 1) + u)];
+                        for (int u = 0; u < 4; ++u) an[u] = va[BT_IDX(4 * (4 * (tt + 1) + u))];
                     }
                     __builtin_amdgcn_sched_barrier(0);       // keep the reads ahead of the MFMAs (the scheduler sinks them to their uses)
                     w0 = __builtin_amdgcn_mfma_f64_16x16x4f64(ac[0], z[4 * tt], w0, 0, 0, 0);
@@ -2132,7 +2138,7 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
             d4 x = {0.0, 0.0, 0.0, 0.0};
             double bc[4], bn[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) bc[m] = vb[(size_t)4 * m * LDV + 16 * BETA];
+            for (int m = 0; m < 4; ++m) bc[m] = vb[BT_IDX((size_t)4 * m * LDV + 16 * BETA)];
 #pragma unroll
             for (int m = 0; m < 4; ++m) x = __builtin_amdgcn_mfma_f64_16x16x4f64(tq[m], w0[m], x, 0, 0, 0);
             // 3. Z^T -= V W'^T
@@ -2140,7 +2146,7 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
             for (int tt = BETA; tt < NT; ++tt) {
                 if (tt + 1 < NT) {
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) bn[m] = vb[(size_t)4 * m * LDV + 16 * (tt + 1)];
+                    for (int m = 0; m < 4; ++m) bn[m] = vb[BT_IDX((size_t)4 * m * LDV + 16 * (tt + 1))];
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 d4 c = {z[4 * tt], z[4 * tt + 1], z[4 * tt + 2], z[4 * tt + 3]};
