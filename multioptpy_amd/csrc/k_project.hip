@@ -129,20 +129,32 @@ __global__ void __launch_bounds__(256) k_proj_w(int n, const double *__restrict_
 
 // M = Q W (6x6), W' = W - 0.5 Q^T M.  One workgroup per image.
 __global__ void __launch_bounds__(256) k_proj_fix(int n, const double *__restrict__ Q, double *__restrict__ W) {
-    __shared__ double red[6 * 16];
+    __shared__ double red[36 * 16];
     __shared__ double M[6][6];
     const int b = blockIdx.x;
     const double *q = Q + (size_t)b * 6 * n;
     double *w = W + (size_t)b * n * 6;
-    for (int k = 0; k < 6; ++k) {
-        double d[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            double qk = q[k * n + i];
+    {
+        // M = Q W: all 36 dot products in one pass and one block reduction (six passes with a barrier each before)
+        double d[36];
 #pragma unroll
-            for (int l = 0; l < 6; ++l) d[l] += qk * w[i * 6 + l];
+        for (int e = 0; e < 36; ++e) d[e] = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            double wl[6];
+#pragma unroll
+            for (int l = 0; l < 6; ++l) wl[l] = w[i * 6 + l];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const double qk = q[k * n + i];
+#pragma unroll
+                for (int l = 0; l < 6; ++l) d[k * 6 + l] += qk * wl[l];
+            }
         }
-        block_sum<6>(d, red);
-        if (threadIdx.x == 0) for (int l = 0; l < 6; ++l) M[k][l] = d[l];
+        block_sum<36>(d, red);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int e = 0; e < 36; ++e) M[e / 6][e % 6] = d[e];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
