@@ -1,7 +1,8 @@
 // Batched symmetric eigen-solver, reduction route (LAPACK dsytrd / dstebz / dstein / dormtr restated for gfx950):
 //   tridiagonalisation A = Q T Q^T, reflectors kept in the rows of A -- three forms, chosen by mopt_launch_eigh_tridiag:
-//     k_tri_persist2<CH,TR>  ONE launch for all n-1 Householder steps, 8 workgroups per matrix, rows on chip (registers
-//                            when TR > 0, LDS otherwise), tagged-word hand-off between the workgroups (the default)
+//     k_tri_persist3<CH,TR>  ONE launch for all n-1 Householder steps, 8-32 workgroups per matrix on one XCD, rows on chip
+//                            (registers when TR > 0, LDS otherwise), row-wise matrix-vector product, tagged-word hand-off
+//                            between the workgroups (the default);  k_tri_persist2: its predecessor (MOPT_TRI_P3=0)
 //     k_tri_step             one launch per Householder step, 8 workgroups per matrix (large n, large batches)
 //     k_tridiag              one workgroup per matrix (n < 32);   k_tri_persist: the first persistent form (MOPT_TRI_PERSIST1)
 //   k_tri_bisect     splitting at negligible off-diagonals, nine-section Sturm search, 8 lanes per eigenvalue
@@ -9,7 +10,8 @@
 //   k_tri_clusters   tight (1e-7) and loose (1e-3) cluster tables
 //   k_tri_invit      inverse iteration (dlagtf / dlagts pivoted tridiagonal LU), one wave per tight cluster
 //   k_tri_lowdin     symmetric orthogonalisation of the loose clusters (independently iterated vectors)
-//   k_tri_backtrans  V = Q Z: 16 lanes per eigenvector, reflectors staged through LDS in blocks
+//   k_tri_larft + k_tri_backtrans_mfma   V = Q Z in compact-WY blocks of 16 reflectors on the FP64 matrix cores (n <= 384)
+//   k_tri_backtrans  V = Q Z on the vector ALUs: 16 lanes per eigenvector, reflectors staged through LDS in blocks
 //   k_tri_sort       ascending order + status
 // ~ (4/3 + 2) n^3 flops instead of the ~70 n^3 of the Jacobi route (k_eigh.hip); same output contract:
 // W ascending, perm, Vt vector-major, einfo.  Developer switches (environment): MOPT_TRI_PROF, MOPT_TRI_NOPERSIST,
@@ -2202,9 +2204,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     };
     const bool g_forced = getenv("MOPT_TRI_G") != nullptr;      // experiment: register-resident rows with a forced group size
     while (!g_forced && G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
-    // More workgroups per matrix when CUs are idle (few matrices per GPU) do not pay: measured at n = 300 with 4-16 matrices,
-    // G = 8 / 16 / 32 -> poll 1.9 / 2.8 / 4.5 us per step against 1.9 / 1.5 / 1.3 us for LDS pass + barrier.  MOPT_TRI_GMAX
-    // (default 8) raises the cap for experiments.
+    // More workgroups per matrix when CUs are idle (few matrices per GPU) did not pay for k_tri_persist2, whose exchange grows with
+    // G: measured at n = 300 with 4-16 matrices, G = 8 / 16 / 32 -> poll 1.9 / 2.8 / 4.5 us per step against 1.9 / 1.5 / 1.3 us for
+    // LDS pass + barrier.  MOPT_TRI_GMAX overrides the cap.
     {
         // k_tri_persist3 exchanges n values per step whatever G is, so idle CUs do pay there: n = 300, 4 or 8 matrices (a band
         // sharded over 8 or 4 GPUs): G = 8 / 16 / 32 -> 0.614 / 0.602 / 0.555 ms.
