@@ -119,6 +119,8 @@ struct mopt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;              // helper stream for work that is independent of the main chain (fork/join by events)
+    hipStream_t side2 = nullptr;             // second helper stream (T factors of the back-transformation)
+    hipEvent_t ev_fork4 = nullptr, ev_join4 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     std::string err;
     bool timing = false;

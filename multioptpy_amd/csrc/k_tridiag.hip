@@ -1541,7 +1541,9 @@ __global__ void __launch_bounds__(256) k_tri_clusters(int n, int batch, const do
             if (fabs(ei) <= 32.0 * DEPS * (fabs(D[i]) + fabs(D[i + 1])) || fabs(ei) < DTINY) E[i] = 0.0;
         } else E[i] = 0.0;
         const bool first = (i == bstart[i]);
-        const double gap = first ? 0.0 : fabs(WT[i] - WT[i - 1]);
+        const int mblk = bend_[(size_t)b * n + i] - bstart[i];
+        const bool small = (mblk >= 2 && mblk <= small_max);       // solved by k_tri_small, possibly still running: its eigenvalues are not read
+        const double gap = (first || small) ? 0.0 : fabs(WT[i] - WT[i - 1]);
         flg[i] = (first || gap > TRI_TIGHT * onenrm[i]) ? 1 : 0;
         flgL[i] = (first || gap > 1e-3 * onenrm[i]) ? 1 : 0;
     }
@@ -2400,9 +2402,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     double *bt_T = d_Z2 + (size_t)batch * n * n;
     if (bt_mfma) {
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
-        hipLaunchKernelGGL(k_tri_larft, dim3(bt_NB, batch), dim3(256), ((size_t)16 * (n | 1) + 2 * 16 * 17 + 16) * 8, ctx->side, n, bt_NB, d_A, d_TAU, bt_T);
-        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_tri_larft, dim3(bt_NB, batch), dim3(256), ((size_t)16 * (n | 1) + 2 * 16 * 17 + 16) * 8, ctx->side2, n, bt_NB, d_A, d_TAU, bt_T);
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));
     }
     int small_max = getenv("MOPT_TRI_SMALL") ? atoi(getenv("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
     if (small_max > TRI_SMALL) small_max = TRI_SMALL;
@@ -2411,8 +2413,15 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         mopt_scope sc(ctx, "eigh_bisect", 1);
         hipLaunchKernelGGL(k_tri_bisect, dim3((n + BIS_PER_WG - 1) / BIS_PER_WG, batch), dim3(BIS_THREADS), (size_t)3 * n * 8 + (size_t)2 * n * 4,
                            ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm, small_max);
-        if (small_max > 0)
-            hipLaunchKernelGGL(k_tri_small, dim3(n, batch), dim3(64), 0, ctx->stream, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
+        if (small_max > 0) {
+            // The small blocks and the larger ones are disjoint in eigenvalues (WT), eigenvector rows (Zt) and the off-diagonals
+            // they read: the wave-level Jacobi runs on the side stream next to cluster tables, inverse iteration and Loewdin
+            // passes of the larger blocks (k_tri_clusters does not read the eigenvalues of small blocks); joined before V = Q Z.
+            MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork4, ctx->stream));
+            MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork4, 0));
+            hipLaunchKernelGGL(k_tri_small, dim3(n, batch), dim3(64), 0, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
+            MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join4, ctx->side));
+        }
         hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)2 * n * 4, ctx->stream, n, batch, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl,
                            (const int *)d_bend, small_max, d_perm, d_info);
     }
@@ -2434,6 +2443,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                                d_Vt, d_Z2, small_max, (const int *)d_perm, (const int *)d_info);
         }
     }
+    if (small_max > 0) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join4, 0));      // the small blocks' eigenpairs (side stream)
     if (bt_mfma) {
         // blocked form on the matrix cores; the T factors (behind the n^2 doubles per matrix of d_Z2) were formed on the side stream
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));

@@ -28,7 +28,13 @@ extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
         hipEventCreateWithFlags(&c->ev_fork2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork4, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev_join3) hipEventDestroy(c->ev_join3);
+        if (c->ev_fork4) hipEventDestroy(c->ev_fork4);
+        if (c->side2) hipStreamDestroy(c->side2);
         if (c->ev_join2) hipEventDestroy(c->ev_join2);
         if (c->ev_fork3) hipEventDestroy(c->ev_fork3);
         if (c->ev_fork) hipEventDestroy(c->ev_fork);
@@ -55,6 +61,9 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipStreamSynchronize(ctx->side);
     hipEventDestroy(ctx->ev_fork); hipEventDestroy(ctx->ev_join); hipEventDestroy(ctx->ev_fork2); hipEventDestroy(ctx->ev_join2);
     hipEventDestroy(ctx->ev_fork3); hipEventDestroy(ctx->ev_join3);
+    hipStreamSynchronize(ctx->side2);
+    hipEventDestroy(ctx->ev_fork4); hipEventDestroy(ctx->ev_join4);
+    hipStreamDestroy(ctx->side2);
     hipStreamDestroy(ctx->side);
     hipStreamDestroy(ctx->stream);
     delete ctx;
