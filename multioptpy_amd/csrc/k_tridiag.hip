@@ -1380,7 +1380,7 @@ __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double 
 // which made one wave per cluster the critical path of the whole stage (100-200 us).  Jacobi does not care about
 // degeneracy: G = (T + sigma I) V is orthogonalised by plane rotations, m/2 disjoint column pairs per round on 4 lanes each
 // (round-robin tournament), eigenvalues are Rayleigh quotients, V is orthogonal by construction.
-constexpr int TRI_SMALL = 32;
+constexpr int TRI_SMALL = 64;
 __device__ __forceinline__ double quad_sum(double v) {
     v += dpp_f64z<0xB1>(v);                // quad_perm [1,0,3,2]
     v += dpp_f64z<0x4E>(v);                // quad_perm [2,3,0,1]
@@ -1396,27 +1396,33 @@ __device__ __forceinline__ double fast_rsqrt(double w) {
     y = fma(0.5 * y, e, y);
     return y;
 }
-__global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
+template <int MAXM, int MINM>
+__global__ void __launch_bounds__(MAXM * 2) k_tri_small(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
                                                   const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_,
                                                   int *__restrict__ fail_) {
     // column stride mp = m | 1 doubles (odd): the 16 column pairs of a round then start in 16 different bank groups; with
     // the natural stride of m = 32 doubles (256 B) every column starts in bank 0 and each LDS access is a 16-way conflict
-    __shared__ double Gs[TRI_SMALL * (TRI_SMALL + 1)], Vs[TRI_SMALL * (TRI_SMALL + 1)];
+    // MAXM = 32: one wave; MAXM = 64: two waves (4 lanes per column pair either way), blocks of MINM .. MAXM rows.
+    extern __shared__ __attribute__((aligned(16))) double smj[];
+    double *Gs = smj, *Vs = smj + MAXM * (MAXM + 1);
     __shared__ int s_rot;
-    const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;
+    __shared__ double s_sig, s_c2[2];
+    const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;           // (lane: thread of the workgroup, 0 .. 2 MAXM - 1)
+    constexpr int NTH = 2 * MAXM;
     const int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n;
     if (bstart[i0] != i0) return;
     const int s = i0, t = bend[i0], m = t - s;
-    if (m < 2 || m > TRI_SMALL) return;
+    if (m < MINM || m > MAXM) return;
     const int mp = m | 1;
     const double *D = D_ + (size_t)b * n + s, *E = E_ + (size_t)b * n + s;
     double *WT = WT_ + (size_t)b * n, *Zt = Zt_ + (size_t)b * n * n;
     // sigma = 1.0625 ||T||_inf: T + sigma I is positive definite with condition number <= 33
     double rs = 0.0;
     if (lane < m) rs = fabs(D[lane]) + (lane > 0 ? fabs(E[lane - 1]) : 0.0) + (lane < m - 1 ? fabs(E[lane]) : 0.0);
-    const double nrm = wave_max(rs);
-    const double sigma = (nrm > 0.0) ? 1.0625 * nrm : 1.0;
-    for (int e = lane; e < m * m; e += WAVE) {
+    if (lane < 64) { const double nrm = wave_max(rs); if (lane == 0) s_sig = (nrm > 0.0) ? 1.0625 * nrm : 1.0; }      // (m <= 64: the rows sit in the first wave)
+    __syncthreads();
+    const double sigma = s_sig;
+    for (int e = lane; e < m * m; e += NTH) {
         const int c = e / m, r = e - c * m;                  // column c, row r
         double g = 0.0;
         if (r == c) g = D[c] + sigma; else if (r == c + 1) g = E[c]; else if (r + 1 == c) g = E[r];
@@ -1426,7 +1432,7 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
     __syncthreads();
     const int me = (m + 1) & ~1, npair = me >> 1;            // an odd block gets a bye
     const int pi = lane >> 2, r4 = lane & 3;
-    constexpr int KP = TRI_SMALL / 4;                        // rows per lane of a pair
+    constexpr int KP = MAXM / 4;                             // rows per lane of a pair
     bool converged = false;
     for (int sweep = 0; sweep < 40 && !converged; ++sweep) {
         if (lane == 0) s_rot = 0;
@@ -1480,10 +1486,17 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
         }
         // Jacobi converges quadratically: a sweep whose columns all met at cosines below 1e-8 leaves them at ~1e-16, the
         // rotation threshold itself -- the sweeps that would only confirm this (one or two of five to seven) are not run
-        converged = (s_rot == 0) || (wave_max(cos2max) < 1e-16);
+        {
+            const double c2 = wave_max(cos2max);
+            if ((lane & 63) == 0) s_c2[lane >> 6] = c2;
+            if (NTH == 64 && lane == 0) s_c2[1] = 0.0;
+        }
+        __syncthreads();
+        converged = (s_rot == 0) || (fmax(s_c2[0], s_c2[1]) < 1e-16);
         __syncthreads();
     }
     if (!converged && lane == 0) atomicAdd(&fail_[b], 1);
+    if (lane < 64) {
     // eigenpairs: column c -> eigenvalue v.g / v.v - sigma, eigenvector v / |v| into row s + c of Zt (zero outside the block)
     for (int c = 0; c < m; ++c) {
         double vg = 0.0, vv = 0.0;
@@ -1493,6 +1506,7 @@ __global__ void __launch_bounds__(64) k_tri_small(int n, const double *__restric
         const double inv = 1.0 / sqrt(vv);
         for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Vs[c * mp + (i - s)] * inv : 0.0;
         if (lane == 0) WT[s + c] = vg / vv - sigma;
+    }
     }
 }
 
@@ -2419,7 +2433,16 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             // passes of the larger blocks (k_tri_clusters does not read the eigenvalues of small blocks); joined before V = Q Z.
             MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork4, ctx->stream));
             MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork4, 0));
-            hipLaunchKernelGGL(k_tri_small, dim3(n, batch), dim3(64), 0, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
+            // (two instantiations: one wave for blocks of 2 .. 32 rows, two waves for 33 .. 64 rows -- the Hessians of a long NEB
+            // run grow blocks of 33-48 rows around a ~20-fold eigenvalue, which cost the inverse iteration 2-3 ms per cluster)
+            static int small_attr = 0;
+            if (!small_attr) {
+                MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_small<64, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+                small_attr = 1;
+            }
+            hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
+            if (small_max > 32)
+                hipLaunchKernelGGL((k_tri_small<64, 33>), dim3(n, batch), dim3(128), (size_t)2 * 64 * 65 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
             MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join4, ctx->side));
         }
         hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)2 * n * 4, ctx->stream, n, batch, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl,
