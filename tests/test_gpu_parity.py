@@ -340,7 +340,7 @@ def test_rsprfo_traces_vs_reference():
 
 
 @pytest.mark.parametrize("algo", ["tridiag", "jacobi", "tridiag-stepwise", "tridiag-persistent", "tridiag-nosmall", "tridiag-persist2",
-                                  "tridiag-valubacktrans", "tridiag-group8"])
+                                  "tridiag-valubacktrans", "tridiag-group8", "tridiag-small32"])
 def test_eigh_forced_route(ops, algo):
     """Both eigen-solvers forced for every size (MOPT_EIGH_ALGO): random, degenerate, clustered and LJ matrices.
     (By default the reduction route runs from n = 32 on and the Jacobi sweeps below.)"""
@@ -365,6 +365,8 @@ lam = np.concatenate([np.ones(20), 1 + 1e-9 * rng.normal(size=20), np.linspace(2
 mats["clustered"] = (Q * lam) @ Q.T
 x100 = cases.cluster(100)
 mats["lj100"] = pj.project_hessian_trrot(cases.lj(x100, hessian=True)[2], x100)
+# identity + rank-20 update: the reduced form has unreduced blocks of 30-50 rows around a many-fold eigenvalue 1 (late NEB steps)
+U = rng.normal(size=(150, 20)); mats["ident_lowrank"] = np.eye(150) + 0.3 * (U * rng.normal(size=20)) @ U.T / 150
 bad = 0
 for name, A in mats.items():
     w, v = ops.eigh(A)
@@ -387,7 +389,8 @@ sys.exit(bad)
 '''
     extra = {"tridiag-stepwise": {"MOPT_TRI_NOPERSIST": "1"}, "tridiag-persistent": {"MOPT_TRI_FORCEPERSIST": "1"},
              "tridiag-nosmall": {"MOPT_TRI_SMALL": "0"}, "tridiag-persist2": {"MOPT_TRI_P3": "0"},
-             "tridiag-valubacktrans": {"MOPT_BT_MFMA": "0"}, "tridiag-group8": {"MOPT_TRI_GMAX": "8"}}.get(algo, {})
+             "tridiag-valubacktrans": {"MOPT_BT_MFMA": "0"}, "tridiag-group8": {"MOPT_TRI_GMAX": "8"},
+             "tridiag-small32": {"MOPT_TRI_SMALL": "32"}}.get(algo, {})
     env = dict(os.environ, MOPT_EIGH_ALGO=algo.split("-")[0], **extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     print(r.stdout)
