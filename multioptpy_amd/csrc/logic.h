@@ -386,12 +386,14 @@ template <class R>
 MOPT_HD double solve_rfo(const R &red, const double *w, const double *gt, int m, double alpha, double *step,
                          double *norm2, int *iters, double *cg2 = nullptr, double *cw = nullptr) {
     double lam = solve_secular(red, w, gt, m, alpha, iters, cg2, cw);
-    red.for_each(m, [=](int i) {
+    // step and its squared norm in one pass (every index is visited by exactly one lane, which squares what it just wrote)
+    *norm2 = red.sum(m, [=](int i) {
         double den = safe_den(w[i] / alpha - lam, 1e-20);
-        step[i] = -(gt[i] / alpha) / den;
+        double v = -(gt[i] / alpha) / den;
+        step[i] = v;
+        return v * v;
     });
     red.sync();
-    *norm2 = red.sum(m, [=](int i) { return step[i] * step[i]; });
     return lam;
 }
 
