@@ -9,7 +9,7 @@
 #include <new>
 
 #include "pipeline.h"
-#include "neb_tr.cuh"
+#include "neb_tr.hpp"
 
 namespace mopt {
 

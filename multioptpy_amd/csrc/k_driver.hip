@@ -5,7 +5,7 @@
 // One workgroup per problem: these run once per optimizer step on O(n^2) / O(N) data.
 #include <cstring>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "pipeline.h"
 
 namespace mopt {

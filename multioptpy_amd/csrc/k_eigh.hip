@@ -9,7 +9,7 @@
 // One workgroup owns a pair of column blocks (2*bw vectors of G and of V) in LDS -- 150 KB of the CU's
 // 160 KB -- and sweeps the pairs inside it with one wave per rotation; a round-robin tournament over
 // the nb blocks gives nb-1 launches per sweep, each with (nb/2) x batch independent workgroups.
-#include "common.cuh"
+#include "common.hpp"
 #include "pipeline.h"
 
 namespace mopt {

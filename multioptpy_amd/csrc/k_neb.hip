@@ -7,7 +7,7 @@
 //   k_ayala        calculate_gamma (pathopt_bneb_force.py:161-222) + H += gamma t t^T (rfo_neb.py:43-74)
 //   k_neb_post     step limit (rfo_neb.py:76-83), TR_calc (trust_radius_neb.py:17-98), FIRE (fire_neb.py:38-92),
 //                  blend (rfo_neb.py:197-206)
-#include "common.cuh"
+#include "common.hpp"
 
 namespace mopt {
 

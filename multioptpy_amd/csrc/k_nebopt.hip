@@ -6,7 +6,7 @@
 #include <cstring>
 
 #include "pipeline.h"
-#include "neb_tr.cuh"
+#include "neb_tr.hpp"
 
 namespace mopt {
 

@@ -7,7 +7,7 @@
 //   k_proj_apply    A -= Q^T W'^T + W' Q  == sym(P^T A P), P = I - Q^T Q   (rank-12 instead of two n^3 GEMMs)
 //   k_proj_grad     g - Q Q^T g with Q from a LAPACK-convention Householder QR of the (n,6) matrix
 //                   (multioptpy/Optimizer/rsirfo.py:128-190)
-#include "common.cuh"
+#include "common.hpp"
 
 namespace mopt {
 

@@ -4,7 +4,7 @@
 //                    secular equation + alpha search (logic.h rs_step), predicted energy, state update
 //   k_backtransform  step = - sum_i coef[i] v_i         (run() returns -move, rsirfo.py:490)
 // Reference: multioptpy/Optimizer/rsirfo.py:285-490, 492-657, 924-1313.
-#include "common.cuh"
+#include "common.hpp"
 #include "logic.h"
 
 namespace mopt {

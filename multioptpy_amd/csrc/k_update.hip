@@ -4,7 +4,7 @@
 //   k_update_coef    dots -> rule coefficients (logic.h update_coefficients), damped y', A = y' - u
 //   k_apply_update   H += dH (rank <= 5 symmetric), then 0.5 (X + X^T): 32x32 tile pairs through LDS
 // Reference: multioptpy/Optimizer/rsirfo.py:1316-1372, hessian_update.py, block_hessian_update.py.
-#include "common.cuh"
+#include "common.hpp"
 #include "logic.h"
 
 namespace mopt {

@@ -2,7 +2,7 @@
 #include <cstring>
 #include <new>
 
-#include "common.cuh"
+#include "common.hpp"
 #include "logic.h"
 #include "pipeline.h"
 

@@ -1,7 +1,7 @@
 // TR_NEB.TR_calc decision for one image (multioptpy/Optimizer/trust_radius_neb.py:17-98), shared by the fused band step
 // (band.hip) and the standalone NEB optimizers (k_nebopt.hip).  Both return the scale applied to delta (0 = frozen).
 #pragma once
-#include "common.cuh"
+#include "common.hpp"
 
 namespace mopt {
 

@@ -1,6 +1,6 @@
 // Internal (non-ABI) interfaces between the translation units of libmopt_hip.so.
 #pragma once
-#include "common.cuh"
+#include "common.hpp"
 #include "logic.h"
 
 #define MOPT_MAX_N 1500            /* 3N; bounded by the LDS staging of the 6 TR/rot vectors (12 n doubles) */

@@ -68,7 +68,7 @@ def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "multioptpy_amd")
     for dp, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cuh", ".cpp")):
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt or f == "__init__.py" and "oracle" not in txt.replace("the oracle", ""), (dp, f)
 
