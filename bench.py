@@ -29,12 +29,42 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector/matrix peak (vendor spec; not in the local guide)
 
 
-def make_trajectory(I, N, nsteps, device):
+def lj_hessians(X):
+    """Exact LJ Hessians of every image (I, n, n), vectorised (same formula as tests/golden/cases.py:lj, which loops in Python)."""
+    import cases
+    I, N = X.shape[0], X.shape[1]
+    out = np.empty((I, 3 * N, 3 * N))
+    eye3 = np.eye(3)
+    for i in range(I):
+        x = X[i]
+        d = x[:, None, :] - x[None, :, :]
+        r2 = np.sum(d * d, axis=2)
+        np.fill_diagonal(r2, 1.0)
+        s2 = cases._RMIN ** 2 / r2
+        s6 = s2 ** 3
+        s12 = s6 ** 2
+        f = cases._EPS * (-12 * s12 + 12 * s6) / r2
+        h2 = cases._EPS * (156 * s12 - 84 * s6) / r2
+        np.fill_diagonal(f, 0.0)
+        np.fill_diagonal(h2, 0.0)
+        blk = ((h2 - f) / r2)[:, :, None, None] * (d[:, :, :, None] * d[:, :, None, :]) + f[:, :, None, None] * eye3
+        H4 = -blk
+        diag = blk.sum(axis=1)
+        for a in range(N):
+            H4[a, a] = diag[a]
+        out[i] = H4.transpose(0, 2, 1, 3).reshape(3 * N, 3 * N)
+    return out
+
+
+def make_trajectory(I, N, nsteps, device, hess0=None):
     """Untimed: run the band optimizer itself for nsteps to obtain realistic per-step inputs (X, E, G)."""
     import cases
     from multioptpy_amd.band import Band
     band = Band(I, N, device=device)
     X = cases.band(I, N)
+    if hess0 is not None:
+        for i in range(I):
+            band.set_hessian(i, hess0[i])
     traj = []
     for it in range(nsteps):
         E = np.zeros(I)
@@ -49,23 +79,16 @@ def make_trajectory(I, N, nsteps, device):
     return traj
 
 
-def cpu_baseline(traj, I, N, budget_s=25.0):
-    """The oracle (NumPy restatement of the reference algorithm incl. its SVD-based B-matrix projection) timed on
-    this host's cores on the first steps of the same trajectory."""
+def _oracle_steps(traj, I, N, budget_s, max_samples, hess0=None):
+    """Run the oracle's RFO-NEB step over the first steps of the trajectory; returns (per-step seconds, new geometries)."""
     import contextlib
     import io
     from oracle import neb as oneb
-    try:
-        from threadpoolctl import threadpool_info
-        thr = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        thr = os.cpu_count() or 1
-    opt = oneb.RFONEB([None] * I)
+    opt = oneb.RFONEB([None] * I if hess0 is None else [h.copy() for h in hess0])
     calc = oneb.BNEB(literal=True)
     preX = preG = None
     pre_vel = []
-    times = []
-    outs = []
+    times, outs = [], []
     t_begin = time.perf_counter()
     for it, (X, E, G) in enumerate(traj):
         t0 = time.perf_counter()
@@ -76,14 +99,64 @@ def cpu_baseline(traj, I, N, budget_s=25.0):
         times.append(dt)
         outs.append(newX)
         preX, preG, pre_vel = X.copy(), G.copy(), F.copy()
-        if it >= 1 and (time.perf_counter() - t_begin) + dt > budget_s:
+        if len(times) - 1 >= max_samples or (it >= 1 and (time.perf_counter() - t_begin) + dt > budget_s):
             break
-    timed = times[1:] if len(times) > 1 else times
+    return times, outs
+
+
+def cpu_baseline(traj, I, N, budget_s=25.0, hess0=None):
+    """The oracle (NumPy restatement of the reference algorithm incl. its SVD-based B-matrix projection) timed on this host's
+    cores on the first steps of the same trajectory, at two BLAS thread settings: 1 thread and a capped all-core
+    setting (the box's CPU share for one GPU is 16 cores; more OpenBLAS threads than that on 300 x 300 problems only
+    oversubscribe).  `value` is the faster of the two medians; both are reported."""
+    from threadpoolctl import threadpool_limits, threadpool_info
+    ncpu = os.cpu_count() or 1
+    cap = int(os.environ.get("MOPT_BENCH_CPU_THREADS", min(ncpu, 16)))
+    blas = sorted({f"{p.get('internal_api')}:{p.get('version')}" for p in threadpool_info()})
+    runs = {}
+    outs = None
+    for thr, share in ((cap, 0.6), (1, 0.4)):
+        with threadpool_limits(limits=thr):
+            times, o = _oracle_steps(traj, I, N, budget_s * share, 20, hess0)
+        if outs is None:
+            outs = o
+        timed = times[1:] if len(times) > 1 else times
+        runs[thr] = {"median_ms": 1e3 * float(np.median(timed)), "min_ms": 1e3 * float(np.min(timed)), "samples": len(timed)}
+    best = min(runs, key=lambda t: runs[t]["median_ms"])
     return {
-        "value": 1e3 * float(np.median(timed)), "unit": "ms/step", "cores": int(thr), "kind": "port",
-        "sample": f"steps 1..{len(times) - 1} of the same {I}x{N} band trajectory (step 0 = warm-up), median; "
-                  f"oracle/neb.py RFONEB with the reference's SVD-based BNEB projection, NumPy/OpenBLAS {thr} threads",
+        "value": runs[best]["median_ms"], "unit": "ms/step", "cores": int(best), "kind": "port",
+        "threads": {str(t): r for t, r in runs.items()}, "host_cpus": ncpu, "blas": blas,
+        "sample": f"steps 1..k of the same {I}x{N} band trajectory (step 0 = warm-up), median of k samples per thread setting "
+                  f"(k <= 20, bounded by --cpu-budget {budget_s:.0f} s split 60/40); oracle/neb.py RFONEB with the reference's "
+                  f"SVD-based BNEB projection; NumPy/BLAS limited to {cap} threads and to 1 thread (threadpoolctl), stdout suppressed, no disk I/O",
     }, outs
+
+
+FAMILIES = ("hess_update", "project", "eigh_init", "eigh_jacobi", "eigh_tridiag", "eigh_bisect", "eigh_invit", "eigh_backtrans",
+            "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post", "halo", "eigh_dc")
+# algorithmic bytes per image-step of a family in units of n^2 (SURVEY.md 8(d): 80 n^2 for the whole RSIRFO.run, of which the
+# eigen-solve's share is input read + eigenvector write; reduction route: the tridiagonalisation reads the matrix once (8 n^2)
+# and leaves the reflectors in its strict upper triangle (4 n^2); the back-transformation reads reflectors + eigenvectors and
+# writes eigenvectors (20 n^2)), and algorithmic flops in units of n^3
+SHARE_BYTES = {"eigh_jacobi": 16.0, "eigh_tridiag": 12.0, "eigh_backtrans": 20.0, "eigh_invit": 8.0, "hess_update": 24.0,
+               "project": 16.0, "rfo": 24.0}
+SHARE_FLOPS = {"eigh_tridiag": 4.0 / 3.0, "eigh_backtrans": 2.0}
+KERNEL_OF = {"eigh_jacobi": "k_jac_step", "eigh_tridiag": "k_tri_persist3", "eigh_backtrans": "k_tri_backtrans_mfma",
+             "eigh_invit": "k_tri_invit", "eigh_bisect": "k_tri_bisect"}
+# what the dominant kernel is actually bound by (DESIGN.md section 5); the HBM and FP64 fractions are reported beside it
+BOUND_NOTE = {"eigh_tridiag": "latency (inter-workgroup hand-off chain of n-1 dependent Householder steps)",
+              "eigh_invit": "latency (sequential inverse iteration inside eigenvalue clusters)",
+              "eigh_bisect": "instruction issue (Sturm recurrences)"}
+
+
+def library_stamp():
+    """Identify the loaded kernel library: sha1 over the HIP sources it was built from (profiles/traffic.json carries the same)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.h*"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
 
 
 def main():
@@ -93,6 +166,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--images", type=int, default=32)
     ap.add_argument("--atoms", type=int, default=100)
+    ap.add_argument("--hessian-init", choices=("identity", "exact"), default="identity",
+                    help="initial per-image Hessians of the band: identity (rfo_neb.py:25) or exact LJ (-fc 1, neb.py:794-804)")
+    ap.add_argument("--no-second-workload", action="store_true", help="skip the short exact-Hessian-start measurement reported beside the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
     args = ap.parse_args()
@@ -124,103 +200,132 @@ def main():
     W, K = max(1, args.warmup), args.steps
     from multioptpy_amd.parallel import shard_bounds, gather_band
     first, count = shard_bounds(I, world, rank)
-
-    # ---- inputs for every step, staged in HBM (untimed)
-    traj = make_trajectory(I, N, W + K, local)
     dev = torch.device("cuda", local)
-    staged = [(torch.from_numpy(X).to(dev), torch.from_numpy(E).to(dev), torch.from_numpy(G).to(dev)) for X, E, G in traj]
-    torch.cuda.synchronize()
 
-    def run(band, timing=False):
-        newx_t = torch.empty((count, N, 3), dtype=torch.float64, device=dev)
-        for k in range(W):
-            dX, dE, dG = staged[k]
-            band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), traj[k][1])
-            band.step(k)
-        band.sync()
-        if timing:
-            band.timing(True)
-        if world > 1:
-            dist.barrier()
+    def measure(hess_init, W, K, want_families):
+        """W warm-up + K timed band steps of the workload; returns (ms per step, family timings, trajectory, Hessians, sweeps)."""
+        hess0 = lj_hessians(cases.band(I, N)) if hess_init == "exact" else None
+        # ---- inputs for every step, staged in HBM (untimed)
+        traj = make_trajectory(I, N, W + K, local, hess0)
+        staged = [(torch.from_numpy(X).to(dev), torch.from_numpy(E).to(dev), torch.from_numpy(G).to(dev)) for X, E, G in traj]
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(W, W + K):
-            dX, dE, dG = staged[k]
-            band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), None)
-            band.step(k)
+
+        def run(band, timing=False):
+            newx_t = [torch.empty((count, N, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+            for k in range(W):
+                dX, dE, dG = staged[k]
+                band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), traj[k][1])
+                band.step(k)
+            band.sync()
+            if timing:
+                band.timing(True)
             if world > 1:
-                band.download_dev(newx_t.data_ptr())
-                band.sync()
-                gather_band(newx_t, I)
-        band.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        return time.perf_counter() - t0
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(W, W + K):
+                dX, dE, dG = staged[k]
+                band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), None)
+                band.step(k)
+                if world > 1:
+                    buf = newx_t[k & 1]              # double-buffered: the gather of step k may still read while step k+1 downloads
+                    band.download_dev(buf.data_ptr())
+                    band.sync()
+                    gather_band(buf, I)
+            band.sync()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            return time.perf_counter() - t0
 
-    band = Band(I, N, first=first, count=count, device=local)
-    elapsed = run(band)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ms_per_step = 1e3 * elapsed / K
-    sweeps = [band.get_state(first + j).jacobi_sweeps for j in range(count)]
-    band.close()
+        def fresh():
+            b = Band(I, N, first=first, count=count, device=local)
+            if hess0 is not None:
+                for i in range(first, first + count):
+                    b.set_hessian(i, hess0[i])
+            return b
+
+        band = fresh()
+        elapsed = run(band)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        sweeps = [band.get_state(first + j).jacobi_sweeps for j in range(count)]
+        band.close()
+        fam = {}
+        if want_families:
+            # the same K steps again on a fresh band with HIP-event timing per kernel family (events on the library's stream;
+            # every rank runs it -- run() contains barriers -- but only rank 0 records and reports)
+            b2 = fresh()
+            run(b2, timing=(rank == 0))
+            if rank == 0:
+                for name in FAMILIES:
+                    ms, nl = b2.timing_read(name)
+                    fam[name] = {"ms_per_step": ms / K, "launches_per_step": nl / K}
+                b2.timing(False)
+            b2.close()
+        return 1e3 * elapsed / K, fam, traj, hess0, sweeps
+
+    ms_per_step, fam, traj, hess0, sweeps = measure(args.hessian_init, W, K, True)
 
     roofline = None
-    fam = {}
-    # ---- roofline leg: the same K steps again on a fresh band with HIP-event timing per kernel family
-    # (every rank runs it -- run() contains barriers -- but only rank 0 records and reports)
-    b2 = Band(I, N, first=first, count=count, device=local)
-    run(b2, timing=(rank == 0))
     if rank == 0:
-        for name in ("hess_update", "project", "eigh_init", "eigh_jacobi", "eigh_tridiag", "eigh_bisect", "eigh_invit", "eigh_backtrans",
-                     "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post"):
-            ms, nl = b2.timing_read(name)
-            fam[name] = {"ms_per_step": ms / K, "launches_per_step": nl / K}
-        b2.timing(False)
         dom = max(fam, key=lambda k: fam[k]["ms_per_step"])
-        # algorithmic bytes: 80 n^2 per image-step for the whole RSIRFO.run, of which the eigen-solve's share
-        # (input read + eigenvector write) is 16 n^2; flops_alg = (20/3) n^3 + 40 n^2 per image-step.
-        # reduction route: the tridiagonalisation reads the matrix once (8 n^2) and leaves the reflectors in its strict upper
-        # triangle (4 n^2); the back-transformation reads reflectors + eigenvectors and writes eigenvectors (20 n^2).
-        share = {"eigh_jacobi": 16.0, "eigh_tridiag": 12.0, "eigh_backtrans": 20.0, "eigh_invit": 8.0, "hess_update": 24.0,
-                 "project": 16.0, "rfo": 24.0}.get(dom, 80.0)
-        kname = {"eigh_jacobi": "k_jac_step", "eigh_tridiag": "k_tri_persist3", "eigh_backtrans": "k_tri_backtrans",
-                 "eigh_invit": "k_tri_invit", "eigh_bisect": "k_tri_bisect"}.get(dom, dom)
+        share = SHARE_BYTES.get(dom, 80.0)
+        kname = KERNEL_OF.get(dom, dom)
         bytes_dom = share * n * n * count
         t_dom = fam[dom]["ms_per_step"] * 1e-3
         ach = bytes_dom / t_dom / 1e9 if t_dom > 0 else 0.0
+        flops_dom = SHARE_FLOPS.get(dom, 0.0) * n ** 3 * count
         flops_step = ((20.0 / 3.0) * n ** 3 + 40.0 * n * n) * count
         step_kernel_ms = sum(v["ms_per_step"] for v in fam.values())
         traffic = None
+        traffic_note = "no PMC figure for this kernel/workload in profiles/traffic.json"
         try:    # HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/profile_bench.sh)
-            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
                 tj = json.load(fh).get(kname)
-            if tj and I == 32 and N == 100 and world == 1:
-                traffic = (tj["fetch_kb_per_launch"] + tj["write_kb_per_launch"]) * 1024.0
+            wl = f"{I}x{N}:{args.hessian_init}"
+            if tj and tj.get("workload", "32x100:identity") == wl and world == 1:
+                # gfx950: FETCH_SIZE counts wide (16 B per lane) reads at half their bytes (MI355X_MICROARCH.md, HBM section);
+                # WRITE_SIZE is exact for 16-byte stores.  Raw counter units are KB.
+                traffic = (2.0 * tj["fetch_kb_per_launch"] + tj["write_kb_per_launch"]) * 1024.0
+                traffic_note = ("2 x FETCH_SIZE (gfx950 wide-read correction) + WRITE_SIZE per launch, bytes; separate rocprofv3 --pmc passes "
+                                f"of round {tj.get('round')} (profiles/traffic.json); raw: fetch {tj['fetch_kb_per_launch']:.0f} KB, "
+                                f"write {tj['write_kb_per_launch']:.0f} KB")
+                if tj.get("source_sha1") not in (None, library_stamp()):
+                    traffic_note += "; NOTE: kernel sources changed since these passes were taken"
         except (OSError, ValueError, KeyError):
             traffic = None
         roofline = {
-            "bound": "hbm", "kernel": kname,
+            "bound": "hbm", "bound_note": BOUND_NOTE.get(dom, "hbm stream"), "kernel": kname,
             "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "FETCH_SIZE + WRITE_SIZE per launch from the committed rocprofv3 PMC passes (profiles/traffic.json), bytes",
-            "alg_bytes_per_step_dominant": bytes_dom, "kernel_ms_per_step": fam[dom]["ms_per_step"],
-            "launches_per_step": fam[dom]["launches_per_step"],
+            "traffic_note": traffic_note,
+            "fp64_frac": (flops_dom / t_dom / 1e12 / FP64_PEAK_TFLOPS) if (t_dom > 0 and flops_dom > 0) else None,
+            "alg_bytes_per_step_dominant": bytes_dom, "alg_flops_per_step_dominant": flops_dom,
+            "kernel_ms_per_step": fam[dom]["ms_per_step"], "launches_per_step": fam[dom]["launches_per_step"],
             # fractions of the whole step are taken over its wall time (ms_per_step of the timed run): the family timers see the
             # main stream only, kernels forked onto the helper streams overlap it and appear in no family
             "whole_step": {"alg_bytes": 80.0 * n * n * count, "alg_flops": flops_step, "kernel_ms": step_kernel_ms, "wall_ms": ms_per_step,
                            "hbm_frac": (80.0 * n * n * count / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if ms_per_step > 0 else 0.0,
                            "fp64_frac": (flops_step / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if ms_per_step > 0 else 0.0},
             "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam.items()},
+            "launches_per_step_all": round(sum(v["launches_per_step"] for v in fam.values()), 1),
         }
 
-    b2.close()
+    # ---- second workload, reported beside the headline line: the same band started from exact LJ Hessians (dense molecular
+    # spectra with the six-fold TR/rot zero cluster: the regime the reference enters this path with, neb.py:794-804)
+    second = None
+    if world == 1 and not args.no_second_workload and args.hessian_init == "identity":
+        K2 = min(K, 10)
+        ms2, fam2, _, _, _ = measure("exact", W, K2, True)
+        if rank == 0:
+            second = {"hessian_init": "exact", "steps": K2, "warmup": W, "ms_per_step": ms2,
+                      "families_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in fam2.items()}}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, outs = cpu_baseline(traj, I, N, args.cpu_budget)
+        cpu, outs = cpu_baseline(traj, I, N, args.cpu_budget, hess0)
         # sanity: the oracle fed with the same inputs reproduces the GPU trajectory's next geometries
         dev_max = 0.0
         for k, nx in enumerate(outs):
@@ -237,10 +342,11 @@ def main():
             "config": {"workload": f"RFO-NEB band step, {I} images x {N} atoms (n={n}), Ar Lennard-Jones surface, "
                                    "block-Bofill/FSB update + TR/rot projection + eigh + RS-I-RFO + BNEB force + TR/FIRE blend",
                        "images": I, "atoms": N, "images_per_gpu": count, "parallelism": f"image-sharded x{world}",
+                       "hessian_init": args.hessian_init,
                        "eigen_solver": "reduction route (tridiagonalise + bisection + inverse iteration)" if max(sweeps) == 0
                                        else "one-sided Jacobi",
                        "jacobi_sweeps_last_step": [int(min(sweeps)), int(max(sweeps))]},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "second_workload": second,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -289,6 +289,32 @@ int mopt_band_download(mopt_band *band, double *newX_angstrom, double *F, double
 int mopt_band_upload_dev(mopt_band *band, const double *dX, const double *dE, const double *dG, const double *E_host);
 int mopt_band_download_dev(mopt_band *band, double *d_newX_angstrom);
 
+/* ---- image-sharded band and its exchange layer ------------------------------------------
+ * One image block per GPU: rank r of R owns images [r I / R, (r + 1) I / R) -- their Hessians, RSIRFO instances
+ * and eigen-solves (rfo_neb.py:137-178) never move.  Per step the ranks exchange, inside the library and on a
+ * dedicated stream per band: the boundary images' coordinates and gradients with rank +- 1 (BNEB tangent,
+ * pathopt_bneb_force.py:67-117; calculate_gamma, rfo_neb.py:63-68; TR_calc, trust_radius_neb.py:36-37), all
+ * energies (extremum_list_index / CI-NEB, pathopt_bneb_force.py:6-17,50-55) and one partial sum per rank of
+ * FIRE's band-wide sum v_prev . F (fire_neb.py:60-65).
+ * Transports: RCCL over xGMI (ncclSend / ncclRecv / ncclAllGather; librccl.so is loaded on first use) for a
+ * multi-process job (one communicator per process from a shared id) or for all devices of one process
+ * (ncclCommInitAll); "peer": plain copies between the bands of one process (hipMemcpyPeerAsync).  Results do not
+ * depend on the transport.
+ * Call sequence per step, for the bands of THIS process that share a communicator group (one band in a
+ * multi-process job): mopt_band_upload_shard[_dev] on each -> mopt_halo_exchange(all) -> mopt_band_step_multi(all). */
+typedef struct mopt_comm mopt_comm;
+#define MOPT_COMM_ID_BYTES 128
+int mopt_comm_unique_id(void *id, int nbytes);                       /* rank 0 of a multi-process job; the host program broadcasts it */
+int mopt_comm_create_rccl_rank(mopt_ctx *ctx, int nranks, int rank, const void *id, mopt_comm **out);
+int mopt_comm_create_rccl_all(int nranks, mopt_ctx *const *ctxs, mopt_comm **outs);   /* one process, ctxs[r] = context of rank r's device */
+int mopt_comm_create_peer(int nranks, mopt_ctx *const *ctxs, mopt_comm **outs);       /* one process, no library (contexts may share a device) */
+int mopt_comm_destroy(mopt_comm *comm);
+int mopt_band_attach_comm(mopt_band *band, mopt_comm *comm);         /* after mopt_band_set_shard; the shard must be the rank's block */
+int mopt_band_upload_shard(mopt_band *band, const double *X_own, const double *E_own, const double *G_own);          /* host, count images */
+int mopt_band_upload_shard_dev(mopt_band *band, const double *dX_own, const double *dE_own, const double *dG_own);   /* device, stream-ordered */
+int mopt_halo_exchange(int nbands, mopt_band *const *bands);
+int mopt_band_step_multi(int nbands, mopt_band *const *bands, int optimize_num);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,17 @@ def _proto(lib):
         lib.mopt_band_download.argtypes = [vp, DP, DP, DP]
         lib.mopt_band_upload_dev.argtypes = [vp, vp, vp, vp, DP]
         lib.mopt_band_download_dev.argtypes = [vp, vp]
+    if hasattr(lib, "mopt_halo_exchange"):
+        lib.mopt_comm_unique_id.argtypes = [vp, C.c_int]
+        lib.mopt_comm_create_rccl_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+        lib.mopt_comm_create_rccl_all.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp)]
+        lib.mopt_comm_create_peer.argtypes = [C.c_int, C.POINTER(vp), C.POINTER(vp)]
+        lib.mopt_comm_destroy.argtypes = [vp]
+        lib.mopt_band_attach_comm.argtypes = [vp, vp]
+        lib.mopt_band_upload_shard.argtypes = [vp, DP, DP, DP]
+        lib.mopt_band_upload_shard_dev.argtypes = [vp, vp, vp, vp]
+        lib.mopt_halo_exchange.argtypes = [C.c_int, C.POINTER(vp)]
+        lib.mopt_band_step_multi.argtypes = [C.c_int, C.POINTER(vp), C.c_int]
 
 
 def lib():

@@ -1,0 +1,40 @@
+// Internal layout of the device-resident NEB band (band.hip) shared with the exchange layer (comm.hip).
+#pragma once
+#include <vector>
+
+#include "pipeline.h"
+
+struct mopt_comm;
+
+struct mopt_band {
+    mopt_ctx *ctx = nullptr;
+    int I = 0, N = 0, n = 0, first = 0, count = 0;
+    double ratio = 0.5;
+    int fix_init = 0, fix_end = 0, apply_ts_opt = 1, apply_ci = 99999;
+    RsirfoWork wk;
+    double *X = nullptr, *G = nullptr, *E = nullptr, *pX = nullptr, *pG = nullptr, *F = nullptr, *pF = nullptr, *tau = nullptr;
+    double *gamma = nullptr, *rfo_delta = nullptr, *newX = nullptr, *wx = nullptr, *wg = nullptr;
+    void *block = nullptr;
+    bool have_prev = false, uploaded = false, opts_init = false, alloc_done = false;
+    bool stepped = false;            // wk.einfo is valid
+    bool have_vecs = false;          // wk.Vt holds the eigenvectors of the previous step (warm start)
+    int warm_run = 0;                // consecutive warm-started solves (a cold solve every 64 re-orthogonalises V)
+    int warm_enabled = 1;
+    std::vector<double> hE;
+    // ---- image-sharded band with an exchange layer (comm.hip): this object owns images [first, first + count) and holds
+    // the neighbours' boundary images (X, G) and all energies after mopt_halo_exchange
+    mopt_comm *comm = nullptr;
+    double *dots = nullptr;          // [MOPT_MAX_RANKS] partial sums of FIRE's band-wide  sum v_prev . F  (slot r: rank r)
+    hipStream_t cst = nullptr;       // dedicated stream of the exchange
+    hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_dot = nullptr, ev_dot_done = nullptr;
+    bool halo_done = false;
+};
+
+#define MOPT_MAX_RANKS 64
+
+int mopt_band_alloc_internal(mopt_band *b);
+int mopt_band_step_phase_a(mopt_band *b, int optimize_num);
+int mopt_band_step_phase_b(mopt_band *b, int optimize_num);
+int mopt_comm_rank(const mopt_comm *c);
+int mopt_comm_nranks(const mopt_comm *c);
+extern "C" int mopt_band_step_multi(int nbands, mopt_band *const *bands, int optimize_num);

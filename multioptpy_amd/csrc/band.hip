@@ -49,6 +49,25 @@ __global__ void __launch_bounds__(256) k_band_take(int nd, int I, const double *
     if (i < I) E[i] = sE[i];
 }
 
+// the same for an image-sharded band: only the owned images arrive (count * n doubles, count energies), stored at their
+// global position
+__global__ void __launch_bounds__(256) k_band_take_shard(int nd, int count, int first, int n, const double *__restrict__ sX,
+                                                         const double *__restrict__ sG, const double *__restrict__ sE,
+                                                         double *__restrict__ X, double *__restrict__ G, double *__restrict__ E) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nd) { X[(size_t)first * n + i] = sX[i]; G[(size_t)first * n + i] = sG[i]; }
+    if (i < count) E[first + i] = sE[i];
+}
+
+// partial sum of FIRE's band-wide switch over the owned images: out[0] = sum_{own} pF . F   (one workgroup: fixed order)
+__global__ void __launch_bounds__(1024) k_band_dot(int nd, size_t off, const double *__restrict__ pF, const double *__restrict__ F, double *__restrict__ out) {
+    __shared__ double red[16];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nd; k += blockDim.x) a += pF[off + k] * F[off + k];
+    a = block_sum1(a, red);
+    if (threadIdx.x == 0) out[0] = a;
+}
+
 // grid = owned images; gamma[local] (0 for end images)
 __global__ void __launch_bounds__(256) k_gamma(int I, int n, int first, const double *__restrict__ X, const double *__restrict__ E,
                                                const double *__restrict__ G, const double *__restrict__ tau,
@@ -105,7 +124,7 @@ __global__ void __launch_bounds__(512) k_neb_post(int I, int N, int first, int o
                                                   int fix_end, const double *__restrict__ X, const double *__restrict__ G,
                                                   const double *__restrict__ F, const double *__restrict__ pF,
                                                   const double *__restrict__ rfo_step, double *__restrict__ rfo_delta_out,
-                                                  double *__restrict__ newX) {
+                                                  double *__restrict__ newX, const double *__restrict__ dots, int ndots) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[6 * 16];
     const int n = 3 * N;
@@ -120,9 +139,15 @@ __global__ void __launch_bounds__(512) k_neb_post(int I, int N, int first, int o
     // ---- FIRE global switch: sum over ALL images of pre_velocity . force (fire_neb.py:60-65)
     double dotp = 0.0;
     if (optimize_num != 0 && have_prev) {
-        double a = 0.0;
-        for (size_t k = threadIdx.x; k < (size_t)I * n; k += blockDim.x) a += pF[k] * F[k];
-        dotp = block_sum1(a, red);
+        if (dots) {
+            // image-sharded band: every rank contributed the sum over its own images (k_band_dot), exchanged by comm.hip;
+            // summed here in rank order on every rank -- the same number everywhere, whatever the transport
+            for (int r = 0; r < ndots; ++r) dotp += dots[r];
+        } else {
+            double a = 0.0;
+            for (size_t k = threadIdx.x; k < (size_t)I * n; k += blockDim.x) a += pF[k] * F[k];
+            dotp = block_sum1(a, red);
+        }
     }
     const bool keep = (optimize_num > 0 && dotp > 0.0 && have_prev);
     // a fresh FIREOptimizer every step (rfo_neb.py:187): dt = 0.5, a = 0.1, n_reset = 0 (never > N_accelerate)
@@ -205,29 +230,13 @@ __global__ void __launch_bounds__(512) k_neb_post(int I, int N, int first, int o
 
 }  // namespace mopt
 
-// ------------------------------------------------------------------------------------------
-struct mopt_band {
-    mopt_ctx *ctx = nullptr;
-    int I = 0, N = 0, n = 0, first = 0, count = 0;
-    double ratio = 0.5;
-    int fix_init = 0, fix_end = 0, apply_ts_opt = 1, apply_ci = 99999;
-    RsirfoWork wk;
-    double *X = nullptr, *G = nullptr, *E = nullptr, *pX = nullptr, *pG = nullptr, *F = nullptr, *pF = nullptr, *tau = nullptr;
-    double *gamma = nullptr, *rfo_delta = nullptr, *newX = nullptr, *wx = nullptr, *wg = nullptr;
-    void *block = nullptr;
-    bool have_prev = false, uploaded = false, opts_init = false, alloc_done = false;
-    bool stepped = false;            // wk.einfo is valid
-    bool have_vecs = false;          // wk.Vt holds the eigenvectors of the previous step (warm start)
-    int warm_run = 0;                // consecutive warm-started solves (a cold solve every 64 re-orthogonalises V)
-    int warm_enabled = 1;
-    std::vector<double> hE;
-};
+#include "band.h"
 
 using namespace mopt;
 
 #define BTRY(x) do { int rc__ = (x); if (rc__ != MOPT_OK) return rc__; } while (0)
 
-static int band_alloc(mopt_band *b) {
+int mopt_band_alloc_internal(mopt_band *b) {
     mopt_ctx *ctx = b->ctx;
     if (b->alloc_done) return MOPT_OK;
     const size_t nv = (size_t)b->I * b->n * 8, cv = (size_t)b->count * b->n * 8;
@@ -241,6 +250,13 @@ static int band_alloc(mopt_band *b) {
     b->E = take((size_t)b->I * 8); take((size_t)b->I * 8);
     b->rfo_delta = take(cv); b->newX = take(cv); b->gamma = take((size_t)b->count * 8);
     BTRY(b->wk.alloc(ctx, b->n, b->count, true, false, false));
+    MOPT_HIP_TRY(ctx, hipMalloc(&b->dots, MOPT_MAX_RANKS * sizeof(double)));
+    MOPT_HIP_TRY(ctx, hipMemsetAsync(b->dots, 0, MOPT_MAX_RANKS * sizeof(double), ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamCreateWithFlags(&b->cst, hipStreamNonBlocking));
+    MOPT_HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+    MOPT_HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_out, hipEventDisableTiming));
+    MOPT_HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_dot, hipEventDisableTiming));
+    MOPT_HIP_TRY(ctx, hipEventCreateWithFlags(&b->ev_dot_done, hipEventDisableTiming));
     // default Hessians: identity (rfo_neb.py:25)
     std::vector<double> eye((size_t)b->n * b->n, 0.0);
     for (int i = 0; i < b->n; ++i) eye[(size_t)i * b->n + i] = 1.0;
@@ -267,6 +283,12 @@ extern "C" int mopt_band_destroy(mopt_band *b) {
     if (!b) return MOPT_E_ARG;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
+    if (b->cst) { hipStreamSynchronize(b->cst); hipStreamDestroy(b->cst); }
+    if (b->ev_in) hipEventDestroy(b->ev_in);
+    if (b->ev_out) hipEventDestroy(b->ev_out);
+    if (b->ev_dot) hipEventDestroy(b->ev_dot);
+    if (b->ev_dot_done) hipEventDestroy(b->ev_dot_done);
+    if (b->dots) hipFree(b->dots);
     if (b->block) hipFree(b->block);
     delete b;
     return MOPT_OK;
@@ -295,7 +317,7 @@ static int band_local(mopt_band *b, int image) {
 extern "C" int mopt_band_set_hessian(mopt_band *b, int image, const double *H) {
     if (!b) return MOPT_E_ARG;
     hipSetDevice(b->ctx->device);
-    BTRY(band_alloc(b));
+    BTRY(mopt_band_alloc_internal(b));
     const int loc = band_local(b, image);
     if (loc < 0) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
@@ -314,7 +336,7 @@ extern "C" int mopt_band_set_hessian(mopt_band *b, int image, const double *H) {
 extern "C" int mopt_band_get_hessian(mopt_band *b, int image, double *H) {
     if (!b || !H) return MOPT_E_ARG;
     hipSetDevice(b->ctx->device);
-    BTRY(band_alloc(b));
+    BTRY(mopt_band_alloc_internal(b));
     const int loc = band_local(b, image);
     if (loc < 0) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
@@ -327,7 +349,7 @@ extern "C" int mopt_band_get_hessian(mopt_band *b, int image, double *H) {
 extern "C" int mopt_band_get_state(mopt_band *b, int image, mopt_rsirfo_state *out) {
     if (!b || !out) return MOPT_E_ARG;
     hipSetDevice(b->ctx->device);
-    BTRY(band_alloc(b));
+    BTRY(mopt_band_alloc_internal(b));
     const int loc = band_local(b, image);
     if (loc < 0) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
@@ -340,7 +362,7 @@ extern "C" int mopt_band_get_state(mopt_band *b, int image, mopt_rsirfo_state *o
 extern "C" int mopt_band_upload(mopt_band *b, const double *X, const double *E, const double *G) {
     if (!b || !X || !E || !G) return MOPT_E_ARG;
     hipSetDevice(b->ctx->device);
-    BTRY(band_alloc(b));
+    BTRY(mopt_band_alloc_internal(b));
     mopt_ctx *ctx = b->ctx;
     const size_t nv = (size_t)b->I * b->n * 8;
     if (b->uploaded) {
@@ -371,16 +393,27 @@ static void band_default_params(mopt_rsirfo_params &p, bool is_end, bool neb_mod
     p.neb_mode = neb_mode ? 1 : 0; p.reserved = 0;
 }
 
-extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
+// One band step in two halves, so that an image-sharded band can exchange FIRE's partial sums between them (comm.hip):
+//   phase A: optimizer (re-)creation, BNEB force of the owned images, the partial sum of  v_prev . F  over the owned images
+//   phase B: Ayala correction, one RSIRFO.run per owned image, step limit + TR_calc + FIRE + blend
+int mopt_band_step_phase_a(mopt_band *b, int optimize_num) {
     if (!b) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
     if (!b->uploaded) { ctx->err = "mopt_band_step: no inputs uploaded"; return MOPT_E_STATE; }
     hipSetDevice(ctx->device);
     const int I = b->I, N = b->N, n = b->n, first = b->first, count = b->count;
     RsirfoWork &wk = b->wk;
+    const bool sharded = (b->comm != nullptr);
+    if (sharded && !b->halo_done) { ctx->err = "mopt_band_step: image-sharded band without mopt_halo_exchange for this step's inputs"; return MOPT_E_STATE; }
+    if (sharded) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, b->ev_out, 0));      // the neighbours' images and all energies have arrived
     if (optimize_num == 0 || !b->opts_init) {
         // rfo_neb.py:112-127: fresh optimizer instances; interior images switch to NEB mode unless they are
         // energy maxima and apply_ts_opt is set
+        if (sharded) {                                       // the energies of the whole band were gathered on the device
+            b->hE.resize(I);
+            MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->hE.data(), b->E, (size_t)I * 8, hipMemcpyDeviceToHost, ctx->stream));
+            MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
         std::vector<mopt_rsirfo_params> ps(count);
         std::vector<mopt_rsirfo_state> ss(count);
         std::vector<int> rules(count);
@@ -405,8 +438,29 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
     const bool have_prev = b->have_prev && optimize_num != 0;
     // (a fill node, not a copy from a host buffer: the step enqueues without waiting for the stream)
     MOPT_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)wk.do_update, have_prev ? 1 : 0, (size_t)count, ctx->stream));
-    // 1. NEB force on the whole band (every shard needs all of F for FIRE's global switch)
-    BTRY(mopt_launch_bneb_force(ctx, I, N, 0, I, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau));
+    // 1. NEB force.  Whole band on one device: all images (FIRE's switch sums over all of F).  Image-sharded: the owned images;
+    //    the switch is assembled from per-rank partial sums.
+    if (!sharded) {
+        BTRY(mopt_launch_bneb_force(ctx, I, N, 0, I, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau));
+    } else {
+        BTRY(mopt_launch_bneb_force(ctx, I, N, first, count, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau));
+        if (have_prev) {
+            mopt_scope sc(ctx, "halo", 1);
+            hipLaunchKernelGGL(k_band_dot, dim3(1), dim3(1024), 0, ctx->stream, count * n, (size_t)first * n, b->pF, b->F, b->dots + mopt_comm_rank(b->comm));
+        }
+        MOPT_HIP_TRY(ctx, hipEventRecord(b->ev_dot, ctx->stream));
+    }
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+int mopt_band_step_phase_b(mopt_band *b, int optimize_num) {
+    mopt_ctx *ctx = b->ctx;
+    hipSetDevice(ctx->device);
+    const int I = b->I, N = b->N, n = b->n, first = b->first, count = b->count;
+    RsirfoWork &wk = b->wk;
+    const bool sharded = (b->comm != nullptr);
+    const bool have_prev = b->have_prev && optimize_num != 0;
     // 2. Ayala curvature correction of the owned interior images
     {
         mopt_scope sc(ctx, "neb_ayala", 2);
@@ -426,12 +480,55 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
     if (rc != MOPT_OK) return rc;
     // 4.-7. step limit, TR_calc, FIRE, blend
     {
+        if (sharded) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, b->ev_dot_done, 0));      // every rank's partial sum has arrived
         mopt_scope sc(ctx, "neb_post", 1);
         hipLaunchKernelGGL(k_neb_post, dim3(count), dim3(512), (size_t)2 * n * 8, ctx->stream, I, N, first, optimize_num,
-                           have_prev ? 1 : 0, b->ratio, b->fix_init, b->fix_end, b->X, b->G, b->F, b->pF, wk.step, b->rfo_delta, b->newX);
+                           have_prev ? 1 : 0, b->ratio, b->fix_init, b->fix_end, b->X, b->G, b->F, b->pF, wk.step, b->rfo_delta, b->newX,
+                           sharded ? (const double *)b->dots : (const double *)nullptr, sharded ? mopt_comm_nranks(b->comm) : 0);
     }
     MOPT_HIP_TRY(ctx, hipGetLastError());
     b->have_prev = true;
+    b->halo_done = false;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
+    if (!b) return MOPT_E_ARG;
+    if (b->comm) { mopt_band *one[1] = {b}; return mopt_band_step_multi(1, one, optimize_num); }
+    BTRY(mopt_band_step_phase_a(b, optimize_num));
+    return mopt_band_step_phase_b(b, optimize_num);
+}
+
+// Inputs of the owned images only (image-sharded band): X_own, G_own: count x N x 3, E_own: count.  The neighbours' boundary images
+// and the other ranks' energies arrive through mopt_halo_exchange.
+extern "C" int mopt_band_upload_shard(mopt_band *b, const double *X_own, const double *E_own, const double *G_own) {
+    if (!b || !X_own || !E_own || !G_own) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(mopt_band_alloc_internal(b));
+    mopt_ctx *ctx = b->ctx;
+    const size_t cv = (size_t)b->count * b->n * 8, off = (size_t)b->first * b->n;
+    if (b->uploaded) { std::swap(b->X, b->pX); std::swap(b->G, b->pG); std::swap(b->F, b->pF); }
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->X + off, X_own, cv, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->G + off, G_own, cv, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->E + b->first, E_own, (size_t)b->count * 8, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->uploaded = true;
+    b->halo_done = false;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_upload_shard_dev(mopt_band *b, const double *dX_own, const double *dE_own, const double *dG_own) {
+    if (!b || !dX_own || !dE_own || !dG_own) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(mopt_band_alloc_internal(b));
+    mopt_ctx *ctx = b->ctx;
+    if (b->uploaded) { std::swap(b->X, b->pX); std::swap(b->G, b->pG); std::swap(b->F, b->pF); }
+    const int nd = b->count * b->n;
+    hipLaunchKernelGGL(mopt::k_band_take_shard, dim3((nd + 255) / 256), dim3(256), 0, ctx->stream, nd, b->count, b->first, b->n, dX_own, dG_own, dE_own,
+                       b->X, b->G, b->E);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    b->uploaded = true;
+    b->halo_done = false;
     return MOPT_OK;
 }
 
@@ -454,7 +551,7 @@ extern "C" int mopt_band_download(mopt_band *b, double *newX_angstrom, double *F
 extern "C" int mopt_band_upload_dev(mopt_band *b, const double *dX, const double *dE, const double *dG, const double *E_host) {
     if (!b || !dX || !dE || !dG) return MOPT_E_ARG;
     hipSetDevice(b->ctx->device);
-    BTRY(band_alloc(b));
+    BTRY(mopt_band_alloc_internal(b));
     mopt_ctx *ctx = b->ctx;
     const size_t nv = (size_t)b->I * b->n * 8;
     if (b->uploaded) { std::swap(b->X, b->pX); std::swap(b->G, b->pG); std::swap(b->F, b->pF); }

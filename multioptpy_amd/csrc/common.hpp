@@ -121,6 +121,8 @@ struct mopt_ctx {
     hipStream_t side = nullptr;              // helper stream for work that is independent of the main chain (fork/join by events)
     hipStream_t side2 = nullptr;             // second helper stream (T factors of the back-transformation)
     hipEvent_t ev_fork4 = nullptr, ev_join4 = nullptr;
+    hipStream_t side3 = nullptr;             // third helper stream (divide-and-conquer chain of the eigen-solver)
+    hipEvent_t ev_fork5 = nullptr, ev_join5 = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     std::string err;
     bool timing = false;
@@ -143,13 +145,13 @@ struct mopt_ctx {
 
 // Scoped timing of a kernel family on the ctx stream (HIP events; only when ctx->timing).
 struct mopt_scope {
-    mopt_ctx *c; const char *name; hipEvent_t a = nullptr, b = nullptr; int n;
-    mopt_scope(mopt_ctx *ctx, const char *nm, int nlaunch = 1) : c(ctx), name(nm), n(nlaunch) {
-        if (c->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, c->stream); }
+    mopt_ctx *c; const char *name; hipEvent_t a = nullptr, b = nullptr; int n; hipStream_t st;
+    mopt_scope(mopt_ctx *ctx, const char *nm, int nlaunch = 1, hipStream_t on = nullptr) : c(ctx), name(nm), n(nlaunch), st(on ? on : ctx->stream) {
+        if (c->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
     }
     ~mopt_scope() {
         if (c->timing) {
-            hipEventRecord(b, c->stream);
+            hipEventRecord(b, st);
             auto &t = c->timers[name];
             t.ev.emplace_back(a, b);
             t.launches += n;

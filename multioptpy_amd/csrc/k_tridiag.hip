@@ -23,6 +23,7 @@
 #include <cstdio>
 #include <vector>
 #include "pipeline.h"
+#include "dc_logic.h"
 
 namespace mopt {
 
@@ -1294,6 +1295,31 @@ __device__ __forceinline__ int sturm_count(const double *d, const double *e2, in
     return cnt;
 }
 
+// Per-matrix switch of the divide-and-conquer solver: 1 when the split tridiagonal (same criterion as k_tri_bisect) keeps an
+// unreduced block of more than dc_min rows.  grid B, block 256, dynamic LDS n ints.  Runs on the helper stream of the D&C chain
+// right behind the tridiagonalisation, so that the chain does not wait for k_tri_bisect.
+__global__ void __launch_bounds__(256) k_dc_flag(int n, const double *__restrict__ D_, const double *__restrict__ E_, int dc_min, int *__restrict__ dcflag_) {
+    extern __shared__ __attribute__((aligned(16))) int cut[];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n;
+    for (int i = tid; i < n; i += blockDim.x) {
+        bool c = true;                                      // cut behind row i
+        if (i < n - 1) { const double ei = E[i]; c = (fabs(ei) <= 32.0 * DEPS * (fabs(D[i]) + fabs(D[i + 1])) || fabs(ei) < DTINY); }
+        cut[i] = c ? 1 : 0;
+    }
+    __syncthreads();
+    int big = 0;
+    for (int i = tid; i < n; i += blockDim.x) {
+        if (i == 0 || cut[i - 1]) {                         // first row of a block: walk to its end
+            int t = i;
+            while (!cut[t]) ++t;
+            big |= (t + 1 - i > dc_min) ? 1 : 0;
+        }
+    }
+    big = __syncthreads_or(big);
+    if (tid == 0) dcflag_[b] = big;
+}
+
 // Eigenvalues by multi-section.  Workgroup (p, b) handles eigenvalues [64 p, 64 p + 64) of matrix b with 512 threads: the
 // 8 lanes of a group probe the 8 interior points of a nine-section of the current interval, each with its own Sturm
 // sequence, so a pass gains log2(9) = 3.17 bits and an eigenvalue takes 17 passes instead of the 53 of plain bisection --
@@ -1304,7 +1330,8 @@ __device__ __forceinline__ int sturm_count(const double *d, const double *e2, in
 // E zeroed at the split points, onenrm per index.   dynamic LDS: 3 n doubles + 2 n ints
 constexpr int BIS_LANES = 8, BIS_THREADS = 512, BIS_PER_WG = BIS_THREADS / BIS_LANES;
 __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double *__restrict__ D_, double *__restrict__ E_, double *__restrict__ WT_,
-                                                            int *__restrict__ bstart_, int *__restrict__ bend_, double *__restrict__ onenrm_, int small_max) {
+                                                            int *__restrict__ bstart_, int *__restrict__ bend_, double *__restrict__ onenrm_, int small_max,
+                                                            int dc_min, int *__restrict__ dcflag_) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *d = sm, *e = sm + n, *e2 = sm + 2 * n;
     int *bs = (int *)(sm + 3 * n), *be = bs + n;
@@ -1334,6 +1361,16 @@ __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double 
     }
     __syncthreads();
     // (the split E is published by a separate tiny kernel: other workgroups of this matrix may still be reading E here)
+    if (dcflag_) {
+        // a matrix with an unreduced block of more than dc_min rows goes to the divide-and-conquer solver (k_dc.hip) as a whole:
+        // nothing of it is computed here, in k_tri_invit or in the Loewdin passes (k_dc_flag on the helper stream takes the same
+        // decision from the same numbers and owns the flag and the block table of such a matrix)
+        int big = 0;
+        if (dc_min > 0) for (int i = tid; i < n; i += blockDim.x) big |= (be[i] - bs[i] > dc_min) ? 1 : 0;
+        big = __syncthreads_or(big);
+        if (blockIdx.x == 0 && tid == 0) dcflag_[b] = big;      // (the same value k_dc_flag writes: for the kernels ordered behind this one)
+        if (big) return;
+    }
     if (blockIdx.x == 0) for (int i = tid; i < n; i += blockDim.x) { bstart[i] = bs[i]; bend[i] = be[i]; }
     const int j = blockIdx.x * BIS_PER_WG + tid / BIS_LANES, sub = tid % BIS_LANES;
     if (j >= n) return;
@@ -1399,7 +1436,8 @@ __device__ __forceinline__ double fast_rsqrt(double w) {
 template <int MAXM, int MINM>
 __global__ void __launch_bounds__(MAXM * 2) k_tri_small(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
                                                   const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_,
-                                                  int *__restrict__ fail_) {
+                                                  int *__restrict__ fail_, const int *__restrict__ dcflag_) {
+    if (dcflag_ && dcflag_[blockIdx.y]) return;              // the whole matrix is solved by k_dc.hip
     // column stride mp = m | 1 doubles (odd): the 16 column pairs of a round then start in 16 different bank groups; with
     // the natural stride of m = 32 doubles (256 B) every column starts in bank 0 and each LDS access is a 16-way conflict
     // MAXM = 32: one wave; MAXM = 64: two waves (4 lanes per column pair either way), blocks of MINM .. MAXM rows.
@@ -1541,10 +1579,15 @@ __device__ __forceinline__ bool loose_cluster_of(int n, int batch, int b, int j,
 __global__ void __launch_bounds__(256) k_tri_clusters(int n, int batch, const double *__restrict__ D_, double *__restrict__ E_,
                                                       const double *__restrict__ WT_, const int *__restrict__ bstart_,
                                                       const double *__restrict__ onenrm_, int *__restrict__ cstart_, int *__restrict__ ncl_,
-                                                      const int *__restrict__ bend_, int small_max, int *__restrict__ wl_, int *__restrict__ wcnt_) {
+                                                      const int *__restrict__ bend_, int small_max, int *__restrict__ wl_, int *__restrict__ wcnt_,
+                                                      const int *__restrict__ dcflag_) {
     extern __shared__ __attribute__((aligned(16))) int flg[];
     int *flgL = flg + n;
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (dcflag_ && dcflag_[b]) {                             // solved by k_dc.hip: no clusters, no work list (and its tables are not read here)
+        if (tid == 0) { ncl_[b] = 0; ncl_[batch + b] = 0; wcnt_[2 * b] = 0; }
+        return;
+    }
     const double *D = D_ + (size_t)b * n, *WT = WT_ + (size_t)b * n, *onenrm = onenrm_ + (size_t)b * n;
     double *E = E_ + (size_t)b * n;
     const int *bstart = bstart_ + (size_t)b * n;
@@ -2183,6 +2226,9 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
 }  // namespace mopt
 
 static int g_tri_attr = 0, g_tri_attr2 = 0;
+size_t mopt_dc_scratch_bytes(int n, int batch);
+int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_D, const double *d_E, int *d_flag, double *d_WT,
+                   double *d_Vt, double *d_Z2, int *d_bstart, int *d_bend, int *d_fail, void *scratch);
 
 // A is destroyed (reflectors are left in its rows).  Work arrays: d_D, d_E, d_TAU, d_WT, d_onenrm: batch*n doubles each;
 // d_Z2: batch*(n*n + MOPT_TRI_T_DOUBLES(n)) doubles (scratch copy of the eigenvectors for the cluster orthogonalisation, then the T factors of the blocked back-transformation).  d_bstart, d_bend: batch*n ints; d_cstart: 2*batch*n ints (tight and loose cluster tables); d_ncl: 2*batch ints; d_fail: batch ints.
@@ -2420,13 +2466,38 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         hipLaunchKernelGGL(k_tri_larft, dim3(bt_NB, batch), dim3(256), ((size_t)16 * (n | 1) + 2 * 16 * 17 + 16) * 8, ctx->side2, n, bt_NB, d_A, d_TAU, bt_T);
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));
     }
+    // divide and conquer (k_dc.hip) for matrices with an unreduced block of more than dc_min rows; MOPT_TRI_DC=0 switches it off
+    const int dc_min = (getenv("MOPT_TRI_DC") && atoi(getenv("MOPT_TRI_DC")) == 0) ? 0 : (getenv("MOPT_TRI_DCMIN") ? atoi(getenv("MOPT_TRI_DCMIN")) : TRI_SMALL);
+    int *d_dcflag = nullptr;
+    if (dc_min > 0 && n > dc_min) {
+        const size_t need = 256 + mopt_dc_scratch_bytes(n, batch) + (size_t)batch * 4;
+        if (ctx->arena_bytes < need) {
+            MOPT_HIP_TRY(ctx, hipDeviceSynchronize());
+            if (ctx->arena) MOPT_HIP_TRY(ctx, hipFree(ctx->arena));
+            ctx->arena = nullptr; ctx->arena_bytes = 0;
+            MOPT_HIP_TRY(ctx, hipMalloc(&ctx->arena, need));
+            ctx->arena_bytes = need;
+        }
+        d_dcflag = (int *)((char *)ctx->arena + 256 + mopt_dc_scratch_bytes(n, batch));
+    }
     int small_max = getenv("MOPT_TRI_SMALL") ? atoi(getenv("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
     if (small_max > TRI_SMALL) small_max = TRI_SMALL;
     if (small_max < 0) small_max = 0;
+    if (d_dcflag) {
+        // divide and conquer for the flagged matrices, the whole chain on its own helper stream (its kernels return at once for
+        // the others; k_tri_clusters / k_tri_invit / k_tri_lowdin on the main stream do the same for the flagged ones)
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork5, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side3, ctx->ev_fork5, 0));
+        hipLaunchKernelGGL(k_dc_flag, dim3(batch), dim3(256), (size_t)n * 4, ctx->side3, n, d_D, d_E, dc_min, d_dcflag);
+        mopt_scope scd(ctx, "eigh_dc", 4 + 5 * mopt::dc_levels(n), ctx->side3);      // (helper stream: overlaps the main-stream families)
+        const int rc = mopt_launch_dc(ctx, ctx->side3, n, batch, d_D, d_E, d_dcflag, d_WT, d_Vt, d_Z2, d_bstart, d_bend, d_fail,
+                                      (char *)ctx->arena + 256);
+        if (rc != MOPT_OK) return rc;
+    }
     {
         mopt_scope sc(ctx, "eigh_bisect", 1);
         hipLaunchKernelGGL(k_tri_bisect, dim3((n + BIS_PER_WG - 1) / BIS_PER_WG, batch), dim3(BIS_THREADS), (size_t)3 * n * 8 + (size_t)2 * n * 4,
-                           ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm, small_max);
+                           ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_onenrm, small_max, dc_min, d_dcflag);
         if (small_max > 0) {
             // The small blocks and the larger ones are disjoint in eigenvalues (WT), eigenvector rows (Zt) and the off-diagonals
             // they read: the wave-level Jacobi runs on the side stream next to cluster tables, inverse iteration and Loewdin
@@ -2440,13 +2511,14 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                 MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_small<64, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
                 small_attr = 1;
             }
-            hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
+            if (small_max > 0)
+                hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
             if (small_max > 32)
-                hipLaunchKernelGGL((k_tri_small<64, 33>), dim3(n, batch), dim3(128), (size_t)2 * 64 * 65 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail);
+                hipLaunchKernelGGL((k_tri_small<64, 33>), dim3(n, batch), dim3(128), (size_t)2 * 64 * 65 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
             MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join4, ctx->side));
         }
         hipLaunchKernelGGL(k_tri_clusters, dim3(batch), dim3(256), (size_t)2 * n * 4, ctx->stream, n, batch, d_D, d_E, d_WT, d_bstart, d_onenrm, d_cstart, d_ncl,
-                           (const int *)d_bend, small_max, d_perm, d_info);
+                           (const int *)d_bend, small_max, d_perm, d_info, (const int *)d_dcflag);
     }
     {
         mopt_scope sc(ctx, "eigh_invit", 1);
@@ -2467,6 +2539,10 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
     }
     if (small_max > 0) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join4, 0));      // the small blocks' eigenpairs (side stream)
+    if (d_dcflag) {                                          // the divide-and-conquer chain (third helper stream)
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join5, ctx->side3));
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
+    }
     if (bt_mfma) {
         // blocked form on the matrix cores; the T factors (behind the n^2 doubles per matrix of d_Z2) were formed on the side stream
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));

@@ -31,7 +31,13 @@ extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
         hipEventCreateWithFlags(&c->ev_join3, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork4, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork5, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join5, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev_fork5) hipEventDestroy(c->ev_fork5);
+        if (c->side3) hipStreamDestroy(c->side3);
+        if (c->ev_join4) hipEventDestroy(c->ev_join4);
         if (c->ev_join3) hipEventDestroy(c->ev_join3);
         if (c->ev_fork4) hipEventDestroy(c->ev_fork4);
         if (c->side2) hipStreamDestroy(c->side2);
@@ -63,6 +69,9 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipEventDestroy(ctx->ev_fork3); hipEventDestroy(ctx->ev_join3);
     hipStreamSynchronize(ctx->side2);
     hipEventDestroy(ctx->ev_fork4); hipEventDestroy(ctx->ev_join4);
+    hipStreamSynchronize(ctx->side3);
+    hipEventDestroy(ctx->ev_fork5); hipEventDestroy(ctx->ev_join5);
+    hipStreamDestroy(ctx->side3);
     hipStreamDestroy(ctx->side2);
     hipStreamDestroy(ctx->side);
     hipStreamDestroy(ctx->stream);

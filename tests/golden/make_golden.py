@@ -261,7 +261,8 @@ def g3_rsprfo():
     from multioptpy.Optimizer import rsprfo
     out = {}
     cfgs = [("rsprfo_bofill", 1, 7, 5, "once", 0), ("rsprfo_bofill", 1, 11, 5, "every", 1), ("rsprfo_bfgs", 0, 7, 4, "once", 2),
-            ("rsprfo_fsb", 1, 22, 4, "once", 3), ("rsprfo_block_bofill", 2, 11, 4, "once", 4), ("rsprfo_bofill", 1, 14, 6, "once", 5)]
+            ("rsprfo_fsb", 1, 22, 4, "once", 3), ("rsprfo_block_bofill", 2, 11, 4, "once", 4), ("rsprfo_bofill", 1, 14, 6, "once", 5),
+            ("rsprfo_bofill", 1, 22, 5, "once", 6)]      # p06: the Diels-Alder-sized P-RFO/Bofill TS search (BASELINE config 3)
     for ci, (method, so, N, nsteps, mode, seed) in enumerate(cfgs):
         tag = f"p{ci:02d}"
         x = cases.cluster(N, seed_offset=seed)
