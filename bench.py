@@ -7,9 +7,10 @@ Metric (BASELINE.json): optimizer-step ms (Hessian update + RFO solve + NEB forc
 One "step" = RFOOptimizer.optimize of the reference (multioptpy/Optimizer/rfo_neb.py:104-208) for the whole band:
 BNEB force, Ayala curvature correction, one RSIRFO.run per image (block-Bofill/FSB update, TR/rot projections,
 symmetric eigen-solve, RS-I-RFO step), step limit, TR_calc, FIRE, blend.  Inputs (geometries, energies, gradients of
-an argon LJ surface, synthetic) for every step are staged in HBM before the timed region; for N > 1 the timed
-region also contains the RCCL all-gather of the new geometries (the exchange a real run needs before the next
-energy/gradient evaluation).
+an argon LJ surface, synthetic) for every step are staged in HBM before the timed region.  For N > 1 every rank is handed
+only its own images' energies and gradients per step (what its calculator would produce); the timed region contains the halo
+exchange a sharded run needs -- neighbour coordinates and gradients, all energies, FIRE's partial sums -- inside the library over
+RCCL (csrc/comm.hip), with no host wait between steps.
 
 Prints ONE JSON line on rank 0.
 """
@@ -198,9 +199,10 @@ def main():
     I, N = args.images, args.atoms
     n = 3 * N
     W, K = max(1, args.warmup), args.steps
-    from multioptpy_amd.parallel import shard_bounds, gather_band
+    from multioptpy_amd.parallel import shard_bounds, halo_exchange, step_multi, rccl_comm_for_process
     first, count = shard_bounds(I, world, rank)
     dev = torch.device("cuda", local)
+    comm = rccl_comm_for_process(local) if world > 1 else None      # RCCL communicator of the library, id broadcast by torch.distributed
 
     def measure(hess_init, W, K, want_families):
         """W warm-up + K timed band steps of the workload; returns (ms per step, family timings, trajectory, Hessians, sweeps)."""
@@ -211,11 +213,20 @@ def main():
         torch.cuda.synchronize()
 
         def run(band, timing=False):
-            newx_t = [torch.empty((count, N, 3), dtype=torch.float64, device=dev) for _ in range(2)]
-            for k in range(W):
+            # world > 1: every rank feeds ONLY its own images (what its calculator would have produced); neighbour coordinates and
+            # gradients, all energies and FIRE's partial sums travel inside the library over RCCL (csrc/comm.hip), on the band's
+            # exchange stream, inside the timed region; nothing waits on the host between steps
+            def one(k):
                 dX, dE, dG = staged[k]
-                band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), traj[k][1])
-                band.step(k)
+                if world > 1:
+                    band.upload_shard_dev(dX[first:first + count].data_ptr(), dE[first:first + count].data_ptr(), dG[first:first + count].data_ptr())
+                    halo_exchange([band])
+                    step_multi([band], k)
+                else:
+                    band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), traj[k][1] if k < W else None)
+                    band.step(k)
+            for k in range(W):
+                one(k)
             band.sync()
             if timing:
                 band.timing(True)
@@ -224,14 +235,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for k in range(W, W + K):
-                dX, dE, dG = staged[k]
-                band.upload_dev(dX.data_ptr(), dE.data_ptr(), dG.data_ptr(), None)
-                band.step(k)
-                if world > 1:
-                    buf = newx_t[k & 1]              # double-buffered: the gather of step k may still read while step k+1 downloads
-                    band.download_dev(buf.data_ptr())
-                    band.sync()
-                    gather_band(buf, I)
+                one(k)
             band.sync()
             torch.cuda.synchronize()
             if world > 1:
@@ -240,6 +244,8 @@ def main():
 
         def fresh():
             b = Band(I, N, first=first, count=count, device=local)
+            if world > 1:
+                b.attach(comm)
             if hess0 is not None:
                 for i in range(first, first + count):
                     b.set_hessian(i, hess0[i])
@@ -349,6 +355,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "second_workload": second,
         }
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -17,8 +17,13 @@ from ..band import Band
 
 
 class RFOOptimizer:
-    def __init__(self, config, persist_hessians=None, device=None):
+    def __init__(self, config, persist_hessians=None, device=None, devices=None, transport="rccl"):
+        """devices=[d0, d1, ...]: image-sharded band, one contiguous image block per listed GPU (the number of images must divide
+        evenly); neighbour coordinates / gradients / energies travel inside the library (RCCL over xGMI, or peer copies with
+        transport="peer").  Default: the whole band on one device."""
         self.config = config
+        self.devices = None if devices is None else list(devices)
+        self.transport = transport
         self.apply_ts_opt = True
         self.ratio_of_rfo_step = getattr(config, "ratio_of_rfo_step", 0.5)
         self.folder = getattr(config, "NEB_FOLDER_DIRECTORY", None)
@@ -54,10 +59,13 @@ class RFOOptimizer:
             if self.band is not None:
                 self.band.close()
             ci = getattr(STRING_FORCE_CALC, "APPLY_CI_NEB", 99999)
-            self.band = Band(I, N, device=self.device, ratio_of_rfo_step=self.ratio_of_rfo_step,
-                             fix_init_edge=getattr(self.config, "fix_init_edge", False),
-                             fix_end_edge=getattr(self.config, "fix_end_edge", False),
-                             apply_ts_opt=self.apply_ts_opt, apply_ci_neb=ci)
+            opts = dict(ratio_of_rfo_step=self.ratio_of_rfo_step, fix_init_edge=getattr(self.config, "fix_init_edge", False),
+                        fix_end_edge=getattr(self.config, "fix_end_edge", False), apply_ts_opt=self.apply_ts_opt, apply_ci_neb=ci)
+            if self.devices is not None and len(self.devices) > 1:
+                from ..parallel import ShardedBand
+                self.band = ShardedBand(I, N, self.devices, transport=self.transport, **opts)
+            else:
+                self.band = Band(I, N, device=self.device if self.devices is None else self.devices[0], **opts)
         if self.persist:
             for i in range(I):
                 f = self._file(i)

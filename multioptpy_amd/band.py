@@ -54,6 +54,21 @@ class Band:
         E = f64(E).reshape(self.I)
         check(lib().mopt_band_upload(self._h, ptr(X), ptr(E), ptr(G)), self._ctx)
 
+    def attach(self, comm):
+        """Join an exchange group (multioptpy_amd.parallel): this band must own the rank's image block."""
+        check(lib().mopt_band_attach_comm(self._h, comm._h), self._ctx)
+        self._comm = comm
+
+    def upload_shard(self, X_own, E_own, G_own):
+        """Inputs of the owned images only (count, N, 3) / (count,); neighbours arrive through parallel.halo_exchange."""
+        X = f64(X_own).reshape(self.count, self.n)
+        G = f64(G_own).reshape(self.count, self.n)
+        E = f64(E_own).reshape(self.count)
+        check(lib().mopt_band_upload_shard(self._h, ptr(X), ptr(E), ptr(G)), self._ctx)
+
+    def upload_shard_dev(self, dX_own, dE_own, dG_own):
+        check(lib().mopt_band_upload_shard_dev(self._h, C.c_void_p(int(dX_own)), C.c_void_p(int(dE_own)), C.c_void_p(int(dG_own))), self._ctx)
+
     def upload_dev(self, dX, dE, dG, E_host=None):
         """Device pointers (ints, e.g. torch.Tensor.data_ptr()) of X (I,N,3), E (I), G (I,N,3) float64."""
         Eh = None if E_host is None else f64(E_host).reshape(self.I)

@@ -148,7 +148,8 @@ def make_band(frames_ang, partition):
 
 
 def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
-                  ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999):
+                  ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999, devices=None,
+                  transport="rccl"):
     """Band relaxation as in nebmain: with FC_COUNT != -1 the Hessian-based branch (`-fc`: RFOOptimizer on a BNEB force),
     otherwise the default FIRE optimizer, replaced by steepest descent from iteration `steepest_descent` on (`-sd`,
     neb.py:794-804, 939-948).
@@ -179,7 +180,8 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
     if quantise:
         geometry_ang = np.array([quantise_xyz(x) for x in geometry_ang])
     STRING_FORCE_CALC = CaluculationBNEB(APPLY_CI_NEB)
-    optimizer = RFOOptimizer(config, persist_hessians=False, device=device) if rfo_branch else FIREOptimizer(config)
+    optimizer = (RFOOptimizer(config, persist_hessians=False, device=device, devices=devices, transport=transport) if rfo_branch
+                 else FIREOptimizer(config))
     tools = Calculationtools()
     pre_geom = pre_gradients = None
     pre_total_velocity = []

@@ -206,7 +206,9 @@ class FIRE:
         self.dt_max = 1.0
         self.fix = (fix_init, fix_end)
 
-    def optimize(self, X, F, pre_vel, optimize_num, vel):
+    def optimize(self, X, F, pre_vel, optimize_num, vel, global_dot=None):
+        """global_dot: the band-wide sum v_prev . F handed in from outside (image-sharded tests: assembled from per-rank
+        partial sums); None = computed here over all images as the reference does."""
         X = np.asarray(X, dtype=float)
         F = np.asarray(F, dtype=float)
         vel = np.asarray(vel, dtype=float)
@@ -222,7 +224,10 @@ class FIRE:
         have_prev = optimize_num != 0 and len(pre_vel) > 1
         dotp = 0.0
         if have_prev:
-            dotp = np.sum([np.dot(pre_vel[i][a], F[i][a].T) for i in range(F.shape[0]) for a in range(F.shape[1])])
+            if global_dot is not None:
+                dotp = global_dot
+            else:
+                dotp = np.sum([np.dot(pre_vel[i][a], F[i][a].T) for i in range(F.shape[0]) for a in range(F.shape[1])])
         if optimize_num > 0 and dotp > 0 and len(pre_vel) > 1:
             if self.n_reset > self.N_acc:
                 self.dt = min(self.dt * self.f_inc, self.dt_max)
@@ -282,7 +287,7 @@ class RFONEB:
         self.opts = []
         self.literal = literal
 
-    def optimize(self, X, G, preX, preG, optimize_num, E, pre_vel, vel, force_calc):
+    def optimize(self, X, G, preX, preG, optimize_num, E, pre_vel, vel, force_calc, fire_dot=None):
         X = np.asarray(X, dtype=float)
         I, N = X.shape[0], X.shape[1]
         maxima = local_maxima(E)
@@ -320,7 +325,7 @@ class RFONEB:
             o.set_hessian(None)
             o.set_bias_hessian(None)
         rfo_mv = tr_calc(X, G, deltas, *self.fix)
-        fire_new = FIRE(*self.fix).optimize(X, projF, pre_vel, optimize_num, vel) / BOHR2ANG
+        fire_new = FIRE(*self.fix).optimize(X, projF, pre_vel, optimize_num, vel, global_dot=fire_dot) / BOHR2ANG
         fire_mv = fire_new - X
         out = []
         for i in range(I):

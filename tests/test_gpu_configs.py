@@ -127,3 +127,152 @@ def test_rsprfo_bofill_n66_trace():
         assert abs(opt.trust_radius - float(z[f"{tag}_s{k}_tr"])) < 1e-12
         assert np.abs(opt.hessian - z[f"{tag}_s{k}_H"]).max() < 1e-8
         assert int(opt.ts_mode_idx) == int(z[f"{tag}_s{k}_tsidx"])
+
+
+# ---- image-sharded band through the exchange layer of the library (csrc/comm.hip) ------------------------------------------
+def _band_inputs(I, N, nsteps, exact):
+    X0 = cases.band(I, N)
+    hess = [cases.lj(X0[i], hessian=True)[2] for i in range(I)] if exact else None
+    return X0, hess
+
+
+@pytest.mark.parametrize("shards", [2, 4])
+def test_sharded_band_peer_transport_matches_whole(shards):
+    """Two / four image blocks as separate shards (all on this one GPU, peer-copy transport): every rank gets ONLY its own images'
+    inputs; neighbour coordinates, gradients, all energies and FIRE's partial sums travel inside the library.  The new geometries
+    and Hessians must equal those of the whole band on one device: bitwise for the steps before FIRE's switch is evaluated from
+    exchanged partial sums, and to 1e-12 afterwards (the sum over ranks is grouped differently from the single-device sum, which
+    only matters through its sign)."""
+    from multioptpy_amd.band import Band
+    from multioptpy_amd.parallel import ShardedBand
+    I, N = 8, 14
+    X0, hess = _band_inputs(I, N, 6, True)
+    whole = Band(I, N)
+    sh = ShardedBand(I, N, [0] * shards, transport="peer")
+    for i in range(I):
+        whole.set_hessian(i, hess[i])
+        sh.set_hessian(i, hess[i])
+    X = X0.copy()
+    for it in range(6):
+        E = np.zeros(I)
+        G = np.zeros((I, N, 3))
+        for i in range(I):
+            E[i], G[i] = cases.lj(X[i])
+        whole.upload(X, E, G)
+        whole.step(it)
+        ref, Fw = whole.download(want_force=True)
+        sh.upload(X, E, G)
+        sh.step(it)
+        got, Fs = sh.download(want_force=True)
+        assert np.array_equal(Fs, Fw), it
+        assert np.abs(got - ref).max() < 1e-12, (it, np.abs(got - ref).max())
+        if it == 0:
+            assert np.array_equal(got, ref)
+        X = ref / cases.BOHR2ANG
+    for i in (0, 3, 4, 7):
+        assert np.abs(sh.get_hessian(i) - whole.get_hessian(i)).max() < 1e-12
+    sh.close()
+    whole.close()
+
+
+def test_sharded_band_rccl_world1():
+    """The RCCL transport on the one GPU of this box (ncclCommInitAll over one device): librccl loads, the communicator is created,
+    exchange and step run through the sharded code path and reproduce the whole band."""
+    from multioptpy_amd.band import Band
+    from multioptpy_amd.parallel import ShardedBand, rccl_comms, halo_exchange, step_multi
+    I, N = 8, 7
+    X0, _ = _band_inputs(I, N, 3, False)
+    whole = Band(I, N)
+    comm = rccl_comms([0])[0]
+    b = Band(I, N, first=0, count=I)
+    b.attach(comm)
+    X = X0.copy()
+    for it in range(3):
+        E = np.zeros(I)
+        G = np.zeros((I, N, 3))
+        for i in range(I):
+            E[i], G[i] = cases.lj(X[i])
+        whole.upload(X, E, G)
+        whole.step(it)
+        ref = whole.download()
+        b.upload_shard(X, E, G)
+        halo_exchange([b])
+        step_multi([b], it)
+        got = b.download()
+        assert np.abs(got - ref).max() < 1e-12, it
+        X = ref / cases.BOHR2ANG
+    b.close()
+    comm.close()
+    whole.close()
+
+
+def test_rfo_optimizer_devices_argument():
+    """RFOOptimizer(devices=[...]) (the plugin surface) on a sharded band equals the single-device optimizer."""
+    from multioptpy_amd.Optimizer.rfo_neb import RFOOptimizer
+    from multioptpy_amd.MEP.pathopt_bneb_force import CaluculationBNEB
+
+    class Cfg:
+        ratio_of_rfo_step = 0.5
+        fix_init_edge = False
+        fix_end_edge = False
+        NEB_FOLDER_DIRECTORY = None
+    I, N = 8, 7
+    X = cases.band(I, N)
+    a = RFOOptimizer(Cfg(), persist_hessians=False)
+    b = RFOOptimizer(Cfg(), persist_hessians=False, devices=[0, 0], transport="peer")
+    calc = CaluculationBNEB()
+    pX = pG = None
+    for it in range(3):
+        E = np.zeros(I)
+        G = np.zeros((I, N, 3))
+        for i in range(I):
+            E[i], G[i] = cases.lj(X[i])
+        ra = a.optimize(X, G, pX, pG, it, E, E, [], [], [], pX, calc)
+        rb = b.optimize(X, G, pX, pG, it, E, E, [], [], [], pX, calc)
+        assert np.abs(np.asarray(ra) - np.asarray(rb)).max() < 1e-12, it
+        pX, pG = X.copy(), G.copy()
+        X = np.asarray(ra) / cases.BOHR2ANG
+    a.band.close()
+    b.band.close()
+
+
+def test_multiprocess_rccl_path_world1():
+    """bench.py's N > 1 path with one rank: the RCCL id travels through torch.distributed, the communicator is created per process,
+    device-pointer shard uploads + in-library exchange + step reproduce the plain band."""
+    import torch
+    import torch.distributed as dist
+    from multioptpy_amd.band import Band
+    from multioptpy_amd.parallel import rccl_comm_for_process, halo_exchange, step_multi
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1")
+    os_env.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        comm = rccl_comm_for_process(0)
+        I, N = 8, 7
+        X = cases.band(I, N)
+        whole = Band(I, N)
+        b = Band(I, N, first=0, count=I)
+        b.attach(comm)
+        dev = torch.device("cuda", 0)
+        for it in range(3):
+            E = np.zeros(I)
+            G = np.zeros((I, N, 3))
+            for i in range(I):
+                E[i], G[i] = cases.lj(X[i])
+            whole.upload(X, E, G)
+            whole.step(it)
+            ref = whole.download()
+            tX, tE, tG = (torch.from_numpy(a).to(dev) for a in (X, E, G))
+            torch.cuda.synchronize()
+            b.upload_shard_dev(tX.data_ptr(), tE.data_ptr(), tG.data_ptr())
+            halo_exchange([b])
+            step_multi([b], it)
+            got = b.download()
+            assert np.abs(got - ref).max() < 1e-12, it
+            X = ref / cases.BOHR2ANG
+        b.close()
+        comm.close()
+        whole.close()
+    finally:
+        dist.destroy_process_group()
