@@ -289,6 +289,20 @@ int mopt_band_download(mopt_band *band, double *newX_angstrom, double *F, double
 int mopt_band_upload_dev(mopt_band *band, const double *dX, const double *dE, const double *dG, const double *E_host);
 int mopt_band_download_dev(mopt_band *band, double *d_newX_angstrom);
 
+/* ---- model Hessians ----------------------------------------------------------------
+ * ApproxHessian.main (multioptpy/ModelHessian/approx_hessian.py:30-112) dispatches by name; on the device:
+ *   MOPT_MODEL_FISCHERD3OLD  FischerD3ApproxHessianOld.main (ModelHessian/fischerd3old.py:355-381), the `-modelhess` default
+ *                            (interface.py:325-330): Fischer-Almloef stretch / bend / torsion force constants on the covalent
+ *                            connectivity + D3(BJ)-style pair terms, symmetrised and TR/rot-projected (Utils/calc_tools.py:249-316).
+ * X: batch x N x 3 (bohr).  par: four arrays of N doubles in a row -- covalent radius, C6, van-der-Waals radius, r4/r2 of every
+ * atom in atomic units (the values of multioptpy/Parameters: covalent_radii_lib, D2_C6_coeff_lib, D2_VDW_radii_lib,
+ * D3Parameters.get_r4r2).  d3: {s6, s8, a1, a2}.  project = 0 skips the TR/rot projection.  H: batch x 3N x 3N. */
+enum { MOPT_MODEL_FISCHERD3OLD = 0 };
+int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H);
+/* The same for the owned images of a band, from the geometries last uploaded, straight into the band's Hessians in HBM
+ * (the reference recomputes the model every -mfc band steps and hands it over in tmp_hessian_{i}.npy, neb.py:515-523). */
+int mopt_band_model_hessian(mopt_band *band, int kind, const double *par, const double *d3);
+
 /* ---- image-sharded band and its exchange layer ------------------------------------------
  * One image block per GPU: rank r of R owns images [r I / R, (r + 1) I / R) -- their Hessians, RSIRFO instances
  * and eigen-solves (rfo_neb.py:137-178) never move.  Per step the ranks exchange, inside the library and on a

@@ -1,0 +1,79 @@
+"""ApproxHessian: drop-in for ``multioptpy.ModelHessian.approx_hessian.ApproxHessian`` (reference approx_hessian.py:26-112).
+
+``main(coord, element_list, cart_gradient, approx_hess_type)`` keeps the reference's signature (coord in bohr) and its dispatch by
+substring.  On the device: the Fischer + D3 model the reference's ``-modelhess`` switch selects by default
+(``fischerd3old``, interface.py:325-330; ModelHessian/fischerd3old.py:355-381) -- ``mopt_model_hessian`` of include/mopt_hip.h.
+Other model names raise NotImplementedError (they are not on the path this package accelerates); there is no CPU fallback.
+
+Per-element parameters (covalent radii, C6, van-der-Waals radii, r4/r2, D3 scaling) are the numbers the reference's
+``multioptpy/Parameters`` functions return, kept as data in ``element_tables.json`` (tools/extract_element_tables.py)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from .. import _lib
+from .._lib import lib, check, f64, ptr
+
+MODEL_FISCHERD3OLD = 0
+_TAB = None
+
+
+def _tables():
+    global _TAB
+    if _TAB is None:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "element_tables.json")) as fh:
+            _TAB = json.load(fh)
+    return _TAB
+
+
+def element_parameters(element_list):
+    """(par, d3): par = [cov | c6 | vdw | r4r2] as one (4 N,) array, d3 = (s6, s8, a1, a2) -- the arguments of the C ABI."""
+    t = _tables()
+    el = t["elements"]
+    try:
+        par = np.concatenate([np.array([el[str(e)][k] for e in element_list], dtype=np.float64) for k in ("cov", "c6", "vdw", "r4r2")])
+    except KeyError as e:
+        raise KeyError(f"no model-Hessian parameters for element {e}") from None
+    d3 = np.array([t["d3"][k] for k in ("s6", "s8", "a1", "a2")], dtype=np.float64)
+    return np.ascontiguousarray(par), d3
+
+
+def model_kind(approx_hess_type):
+    """The reference's substring dispatch (approx_hessian.py:35-97), restricted to what runs on the device."""
+    name = str(approx_hess_type).lower()
+    if "gfnff" in name or "gfn0xtb" in name:
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device")
+    if "fischerd3old" in name:
+        for suffix in ("ts", "sr", "clip"):
+            if suffix in name.replace("fischerd3old", ""):
+                raise NotImplementedError(f"model Hessian modifier '{suffix}' is not available on the device")
+        return MODEL_FISCHERD3OLD
+    raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old)")
+
+
+class ApproxHessian:
+    def __init__(self, device=None):
+        self.device = device
+
+    def main(self, coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
+        kind = model_kind(approx_hess_type)
+        X = f64(coord).reshape(-1, 3)
+        N = X.shape[0]
+        par, d3 = element_parameters(element_list)
+        H = np.empty((3 * N, 3 * N))
+        c = _lib.ctx(self.device)
+        check(lib().mopt_model_hessian(c, kind, N, 1, ptr(X), ptr(par), ptr(d3), 1, ptr(H)), c)
+        return H
+
+    def batch(self, coords, element_list, approx_hess_type="fischerd3old", project=True):
+        """All images of a band in one call: coords (I, N, 3) bohr -> (I, 3N, 3N)."""
+        kind = model_kind(approx_hess_type)
+        X = f64(coords)
+        I, N = X.shape[0], X.shape[1]
+        par, d3 = element_parameters(element_list)
+        H = np.empty((I, 3 * N, 3 * N))
+        c = _lib.ctx(self.device)
+        check(lib().mopt_model_hessian(c, kind, N, I, ptr(X), ptr(par), ptr(d3), 1 if project else 0, ptr(H)), c)
+        return H

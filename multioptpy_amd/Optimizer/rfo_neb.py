@@ -32,6 +32,7 @@ class RFOOptimizer:
         self.band = None
         self.optimizer_instance_list = []     # kept for API compatibility (state lives on the device)
         self._pending_hessians = None         # in-memory counterpart of the tmp_hessian_i.npy side channel
+        self._pending_model = None
 
     def set_apply_ts_opt(self, apply_ts_opt):
         self.apply_ts_opt = apply_ts_opt
@@ -40,6 +41,11 @@ class RFOOptimizer:
         """Hand over one Hessian per image (or None to keep an image's current one) for the next `optimize` call: what the
         calculators do in the reference by writing tmp_hessian_{i}.npy (e.g. lj_calculation_tools.py:350-353)."""
         self._pending_hessians = list(hessians)
+
+    def request_model_hessian(self, element_list, approx_hess_type="fischerd3old"):
+        """The next `optimize` call first replaces every image's Hessian by the model Hessian of its geometry, computed on the
+        device into the band's resident Hessians (the reference: ApproxHessian().main per image + tmp_hessian_{i}.npy, neb.py:515-523)."""
+        self._pending_model = (list(element_list), approx_hess_type)
 
     def get_image_hessian(self, i):
         """The Hessian of image i as the reference would find it in tmp_hessian_{i}.npy after the step."""
@@ -76,6 +82,9 @@ class RFOOptimizer:
                     self.band.set_hessian(i, np.asarray(h, dtype=np.float64))
             self._pending_hessians = None
         self.band.upload(X, E, G)
+        if self._pending_model is not None:
+            self.band.model_hessian(*self._pending_model)
+            self._pending_model = None
         self.band.step(optimize_num)
         newX, F = self.band.download(want_force=True)
         if hasattr(STRING_FORCE_CALC, "tau_list"):

@@ -64,6 +64,9 @@ def _proto(lib):
         lib.mopt_band_download.argtypes = [vp, DP, DP, DP]
         lib.mopt_band_upload_dev.argtypes = [vp, vp, vp, vp, DP]
         lib.mopt_band_download_dev.argtypes = [vp, vp]
+    if hasattr(lib, "mopt_model_hessian"):
+        lib.mopt_model_hessian.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, C.c_int, DP]
+        lib.mopt_band_model_hessian.argtypes = [vp, C.c_int, DP, DP]
     if hasattr(lib, "mopt_halo_exchange"):
         lib.mopt_comm_unique_id.argtypes = [vp, C.c_int]
         lib.mopt_comm_create_rccl_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]

@@ -499,6 +499,25 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
     return mopt_band_step_phase_b(b, optimize_num);
 }
 
+// Model Hessians of the owned images from the uploaded geometries, written straight into the band's device-resident Hessians
+// (the reference computes ApproxHessian().main per image every -mfc steps and passes it through tmp_hessian_i.npy, neb.py:515-523).
+extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par, const double *d3) {
+    if (!b || !par || !d3) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    if (kind != MOPT_MODEL_FISCHERD3OLD) { ctx->err = "mopt_band_model_hessian: unknown model"; return MOPT_E_ARG; }
+    if (!b->uploaded) { ctx->err = "mopt_band_model_hessian: no geometries uploaded"; return MOPT_E_STATE; }
+    hipSetDevice(ctx->device);
+    double *d_par = nullptr;
+    MOPT_HIP_TRY(ctx, hipMalloc((void **)&d_par, (size_t)4 * b->N * 8));
+    hipError_t e = hipMemcpyAsync(d_par, par, (size_t)4 * b->N * 8, hipMemcpyHostToDevice, ctx->stream);
+    int rc = (e == hipSuccess) ? mopt_launch_model_hessian(ctx, b->N, b->count, b->X + (size_t)b->first * b->n, d_par, d3, b->wk.Gt, b->wk.Q, b->wk.W6, b->wk.H, true)
+                               : MOPT_E_DEVICE;
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_par);
+    b->have_vecs = false;
+    return rc;
+}
+
 // Inputs of the owned images only (image-sharded band): X_own, G_own: count x N x 3, E_own: count.  The neighbours' boundary images
 // and the other ranks' energies arrive through mopt_halo_exchange.
 extern "C" int mopt_band_upload_shard(mopt_band *b, const double *X_own, const double *E_own, const double *G_own) {

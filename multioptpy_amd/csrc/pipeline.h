@@ -55,6 +55,9 @@ int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g,
                              bool side_stream = false);
 int mopt_launch_matvec(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_v, double *d_out);
 int mopt_launch_sym_add(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, double *d_A);
+// FischerD3ApproxHessianOld.main for a batch of geometries (k_modelhess.hip); d3 is a HOST array {s6, s8, a1, a2}
+int mopt_launch_model_hessian(mopt_ctx *ctx, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
+                              double *d_W, double *d_A, bool project);
 int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
                      int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps, bool warm);

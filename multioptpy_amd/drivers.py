@@ -57,7 +57,8 @@ class ConvergenceChecker:
 
 
 def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, saddle_order=0, NSTEP=300, FC_COUNT=-1,
-                  max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False):
+                  max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False, model_hessian=None,
+                  MFC_COUNT=50):
     """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy)."""
     natom = len(element_list)
     geometry = np.array(start_geometry_ang, dtype="float64") / BOHR2ANGSTROMS
@@ -92,6 +93,11 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
         geometry = np.array(geom_bohr, dtype="float64")
         Model_hess = copy.deepcopy(calculator.Model_hess)
         energy = e
+        # periodic model Hessian (optimization.py:1884-1907): replaces Model_hess every MFC_COUNT iterations when no exact Hessian is used
+        if model_hessian is not None and it % MFC_COUNT == 0 and FC_COUNT < 1:
+            from .ModelHessian.approx_hessian import ApproxHessian
+            Model_hess = ApproxHessian().main(geometry, element_list, np.asarray(g, dtype="float64"), model_hessian)
+            calculator.Model_hess = Model_hess
         bias_hessian = np.zeros((3 * natom, 3 * natom))
         if it == 0:                                                     # _save_init_geometry (optimization.py:2206-2217)
             centre = tools.calc_center(geometry, element_list)
@@ -99,7 +105,7 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
         # HessianManager.calc_eff_hess_for_fix_atoms_and_set_hess (optimization.py:1311-1365), all atoms active
         for inst in optimizer_instances:
             inst.set_bias_hessian(bias_hessian)
-            if it % FC_COUNT == 0:
+            if it % FC_COUNT == 0 or (model_hessian is not None and it % MFC_COUNT == 0):      # optimization.py:1354-1367
                 inst.set_hessian(Model_hess)
         g_raw = copy.deepcopy(np.asarray(g, dtype="float64"))
         B_g = copy.deepcopy(np.asarray(g, dtype="float64"))
@@ -149,7 +155,7 @@ def make_band(frames_ang, partition):
 
 def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
                   ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999, devices=None,
-                  transport="rccl"):
+                  transport="rccl", model_hessian=None, MFC_COUNT=50):
     """Band relaxation as in nebmain: with FC_COUNT != -1 the Hessian-based branch (`-fc`: RFOOptimizer on a BNEB force),
     otherwise the default FIRE optimizer, replaced by steepest descent from iteration `steepest_descent` on (`-sd`,
     neb.py:794-804, 939-948).
@@ -175,7 +181,8 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
     config.dt, config.a, config.n_reset = 0.5, 0.10, 0                      # NEBConfig defaults (neb.py:213-222)
     config.FIRE_N_accelerate, config.FIRE_f_inc, config.FIRE_f_accelerate = 5, 1.10, 0.99
     config.FIRE_f_decelerate, config.FIRE_a_start, config.FIRE_dt_max = 0.5, 0.1, 1.0
-    rfo_branch = FC_COUNT != -1
+    # neb.py:797: the Hessian-based branch runs with exact Hessians (-fc) or with model Hessians (-modelhess, every -mfc steps)
+    rfo_branch = FC_COUNT != -1 or (MFC_COUNT != -1 and bool(model_hessian))
     geometry_ang = make_band(frames_ang, partition)
     if quantise:
         geometry_ang = np.array([quantise_xyz(x) for x in geometry_ang])
@@ -193,6 +200,8 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
         X = np.asarray(X, dtype="float64")
         if hessians is not None and rfo_branch:
             optimizer.set_image_hessians(hessians)
+        if FC_COUNT == -1 and model_hessian and optimize_num % MFC_COUNT == 0:          # neb.py:515-523
+            optimizer.request_model_hessian(element_list, model_hessian)
         if optimize_num == 0:
             init_geometry = X
         total_force = STRING_FORCE_CALC.calc_force(X, E, G, optimize_num, element_list)

@@ -203,6 +203,10 @@ class ShardedBand:
             b.upload_shard(X[s], E[s], G[s])
         halo_exchange(self.bands)
 
+    def model_hessian(self, element_list, approx_hess_type="fischerd3old"):
+        for b in self.bands:
+            b.model_hessian(element_list, approx_hess_type)
+
     def step(self, optimize_num):
         step_multi(self.bands, optimize_num)
 

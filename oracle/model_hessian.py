@@ -1,0 +1,227 @@
+"""ORACLE (test infrastructure, never imported by the product): NumPy restatement of the reference's model Hessian path
+  ApproxHessian.main                multioptpy/ModelHessian/approx_hessian.py:30-112  (dispatch by substring)
+  FischerD3ApproxHessianOld.main    multioptpy/ModelHessian/fischerd3old.py:355-381   (the `-modelhess` default, interface.py:325-330)
+with its helpers: BondConnectivity (Utils/bond_connectivity.py:7-135), stretch2 / bend2 / torsion2 (ModelHessian/calc_params.py:139-227).
+Pinned by tests/golden/g10_model_hessian.npz (outputs of the reference itself).  Coordinates in bohr."""
+import json
+import os
+
+import numpy as np
+
+from . import projection as pj
+
+_TAB = None
+
+
+def tables():
+    global _TAB
+    if _TAB is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        with open(os.path.join(here, "..", "multioptpy_amd", "ModelHessian", "element_tables.json")) as fh:
+            _TAB = json.load(fh)
+    return _TAB
+
+
+def element_params(element_list):
+    t = tables()["elements"]
+    return {k: np.array([t[e][k] for e in element_list], dtype=float) for k in ("cov", "c6", "vdw", "r4r2")}
+
+
+# ---- connectivity (bond_connectivity.py:14-135) ----------------------------------------------------------------------
+def connect_matrix(coord, cov, factor):
+    d = np.linalg.norm(coord[:, None, :] - coord[None, :, :], axis=2)
+    lim = (cov[:, None] + cov[None, :]) * factor
+    c = d <= lim
+    np.fill_diagonal(c, False)
+    return c
+
+
+def bond_table(C):
+    n = len(C)
+    return [(i, j) for i in range(n) for j in range(i, n) if C[i, j]]
+
+
+def angle_table(C):
+    n = len(C)
+    out = []
+    for i in range(n):
+        for j in range(n):
+            if C[i, j]:
+                for m in range(j + 1, n):
+                    if C[i, m] and not C[j, m]:
+                        out.append((j, i, m))
+    return out
+
+
+def dihedral_table(C, angles):
+    """bond_connectivity.py:69-128: every pair of angles (a before b) sharing a bond yields at most one dihedral, the first of the
+    listed candidates whose outer bond exists; a rule whose candidates both fail lets the next rule try.  Duplicates are kept."""
+    out = []
+    for ia in range(len(angles)):
+        a0, a1, a2 = angles[ia]
+        for ib in range(ia + 1, len(angles)):
+            b0, b1, b2 = angles[ib]
+            head = lambda x: ((x, a0, a1, a2), (1, 0))          # x-a0-a1-a2, needs bond a0-x
+            tail = lambda x: ((a0, a1, a2, x), (2, 3))          # a0-a1-a2-x, needs bond a2-x
+            rules = (
+                ((a1 == b1 and a2 == b2) or (a1 == b2 and a2 == b1), (tail(b0), head(b0))),
+                ((a1 == b1 and a0 == b0) or (a1 == b0 and a0 == b1), (head(b2), tail(b2))),
+                ((a1 == b0 and a2 == b1) or (a1 == b1 and a2 == b0), (tail(b2), head(b2))),
+                ((a0 == b1 and a1 == b2) or (a0 == b2 and a1 == b1), (head(b0), tail(b0))),
+            )
+            done = False
+            for cond, cands in rules:
+                if not cond:
+                    continue
+                for quad, (p, q) in cands:
+                    if C[quad[p], quad[q]]:
+                        out.append(quad)
+                        done = True
+                        break
+                if done:
+                    break
+    return out
+
+
+# ---- Wilson B-vectors (calc_params.py:139-227) -----------------------------------------------------------------------
+def stretch2(x):
+    d = x[0] - x[1]
+    r = np.linalg.norm(d)
+    return r, np.array([-d / r, d / r])
+
+
+def bend2(x):
+    r1, b1 = stretch2(x[0:2])
+    r2, b2 = stretch2(x[1:3])
+    co = float(np.dot(b1[0], b2[1]))
+    crap = float(np.sum(b1[0] ** 2) + np.sum(b2[1] ** 2))
+    if np.sqrt(crap) < 1e-12:
+        fir = np.pi - np.arcsin(np.sqrt(crap))
+        si = np.sqrt(crap)
+    else:
+        fir = np.arccos(co)
+        si = np.sqrt(1 - co ** 2)
+    if abs(fir - np.pi) < 1e-12:
+        fir = np.pi
+    bf = np.zeros((3, 3))
+    d1, d2 = r1 * si, r2 * si
+    if d1 >= 1e-12:
+        bf[0] = (co * b1[0] - b2[1]) / d1
+    if d2 >= 1e-12:
+        bf[2] = (co * b2[1] - b1[0]) / d2
+    bf[1] = -(bf[0] + bf[2])
+    return fir, bf
+
+
+def torsion2(x):
+    r1, bij = stretch2(x[0:2])
+    r2, bjk = stretch2(x[1:3])
+    r3, bkl = stretch2(x[2:4])
+    f2, _ = bend2(x[0:3])
+    f3, _ = bend2(x[1:4])
+    s2, s3, c2, c3 = np.sin(f2), np.sin(f3), np.cos(f2), np.cos(f3)
+    bt = np.zeros((4, 3))
+    bt[0] = np.cross(bij[1], bjk[1]) / (r1 * s2 ** 2)
+    bt[3] = np.cross(bkl[0], bjk[0]) / (r3 * s3 ** 2)
+    bt[1] = -((r2 - r1 * c2) * bt[0] + r3 * c3 * bt[3]) / r2
+    bt[2] = -(bt[0] + bt[1] + bt[3])
+    return bt
+
+
+# ---- FischerD3ApproxHessianOld (fischerd3old.py) ---------------------------------------------------------------------
+def _d3_block(rv, r, c6, c8, r0, d3):
+    """fischerd3old.py:84-131."""
+    a1, a2, s6, s8 = d3["a1"], d3["a2"], d3["s6"], d3["s8"]
+    q6 = (a1 * r0 + a2) ** 6
+    q8 = (a1 * r0 + a2 + 2.0) ** 8
+    den6, den8 = r ** 6 + q6, r ** 8 + q8
+    f6, f8 = r ** 6 / den6, r ** 8 / den8
+    df6 = 6 * r ** 5 / den6 - 6 * r ** 12 / den6 ** 2
+    df8 = 8 * r ** 7 / den8 - 8 * r ** 16 / den8 ** 2
+    g6 = -s6 * c6 * ((-6.0 / r ** 7) * f6 + (1.0 / r ** 6) * df6)
+    g8 = -s8 * c8 * ((-8.0 / r ** 9) * f8 + (1.0 / r ** 8) * df8)
+    u = rv / r
+    P = np.outer(u, u)
+    hpar = s6 * c6 / r ** 8 * (42.0 * f6 - r * df6) + s8 * c8 / r ** 10 * (72.0 * f8 - r * df8)
+    hperp = (g6 + g8) / r
+    return hpar * P + hperp * (np.eye(3) - P)
+
+
+def fischer_d3_old(coord, element_list, project=True):
+    coord = np.asarray(coord, dtype=float).reshape(-1, 3)
+    N = len(coord)
+    par = element_params(element_list)
+    cov = par["cov"]
+    d3 = tables()["d3"]
+    H = np.zeros((3 * N, 3 * N))
+    C11 = connect_matrix(coord, cov, 1.1)                # BondConnectivity: the internal coordinates
+    C13 = connect_matrix(coord, cov, 1.3)                # get_bond_connectivity (bond_factor 1.3): torsion bond counts, D3 exclusions
+    nb13 = C13.sum(axis=1)
+
+    def add(atoms, b, fc):
+        for m, am in enumerate(atoms):
+            for q, aq in enumerate(atoms):
+                H[3 * am:3 * am + 3, 3 * aq:3 * aq + 3] += fc * np.outer(b[m], b[q])
+
+    for i, j in bond_table(C11):                        # fischer_bond, :157-187
+        r = np.linalg.norm(coord[i] - coord[j])
+        fc = 0.3601 * np.exp(-1.944 * (r - (cov[i] + cov[j])))
+        _, b = stretch2(coord[[i, j]])
+        add((i, j), b, fc)
+    angles = angle_table(C11)
+    for i, j, k in angles:                              # fischer_angle, :190-236
+        vij, vjk = coord[i] - coord[j], coord[k] - coord[j]
+        rij, rjk = np.linalg.norm(vij), np.linalg.norm(vjk)
+        if rij < 0.1 or rjk < 0.1:
+            continue
+        if abs(np.dot(vij, vjk) / (rij * rjk)) > 0.9999:
+            continue
+        cij, cjk = cov[i] + cov[j], cov[j] + cov[k]
+        val = cij * cjk
+        fc = 0.0 if abs(val) < 1e-10 else 0.089 + 0.11 / val ** (-0.42) * np.exp(-0.44 * (rij + rjk - cij - cjk))
+        _, b = bend2(coord[[i, j, k]])
+        add((i, j, k), b, fc)
+    for i, j, k, l in dihedral_table(C11, angles):      # fischer_dihedral, :239-325
+        vji, vjk, vkl = coord[i] - coord[j], coord[k] - coord[j], coord[l] - coord[k]
+        rjk = np.linalg.norm(vjk)
+        cjk = cov[j] + cov[k]
+        bsum = int(nb13[j] + nb13[k] - 2)
+        val = rjk * cjk
+        fc = 0.0 if abs(val) < 1e-10 else 0.0015 + 14.0 * max(bsum, 0) ** 0.57 / val ** 4.0 * np.exp(-2.85 * (rjk - cjk))
+        nji, nkl = np.linalg.norm(vji), np.linalg.norm(vkl)
+        if nji < 1e-8 or rjk < 1e-8 or nkl < 1e-8:
+            continue
+        c1 = np.dot(vji, vjk) / (nji * rjk)
+        c2 = np.dot(-vjk, vkl) / (rjk * nkl)
+        s1, s2 = 1.0 - min(c1 ** 2, 1.0), 1.0 - min(c2 ** 2, 1.0)
+        if s1 < 1e-4 or s2 < 1e-4:
+            continue
+        fc *= s1 * s2
+        b = torsion2(coord[[i, j, k, l]])
+        add((i, j, k, l), b, fc)
+    for i in range(N):                                  # d3_dispersion_hessian, :328-352
+        for j in range(i):
+            if C13[i, j]:
+                continue
+            rv = coord[i] - coord[j]
+            r = np.linalg.norm(rv)
+            if r < 0.1:
+                continue
+            c6 = np.sqrt(par["c6"][i] * par["c6"][j])
+            c8 = 3.0 * c6 * np.sqrt(par["r4r2"][i] * par["r4r2"][j])
+            blk = _d3_block(rv, r, c6, c8, par["vdw"][i] + par["vdw"][j], d3)
+            H[3 * i:3 * i + 3, 3 * i:3 * i + 3] += blk
+            H[3 * j:3 * j + 3, 3 * j:3 * j + 3] += blk
+            H[3 * i:3 * i + 3, 3 * j:3 * j + 3] -= blk
+            H[3 * j:3 * j + 3, 3 * i:3 * i + 3] -= blk
+    H = 0.5 * (H + H.T)
+    return pj.project_hessian_trrot(H, coord) if project else H
+
+
+def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
+    """ApproxHessian.main: only the Fischer + D3 (old) model is restated; its substring test precedes 'fischerd3' and 'fischer'
+    in the reference's dispatch (approx_hessian.py:41-46)."""
+    name = approx_hess_type.lower()
+    if "gfnff" in name or "gfn0xtb" in name or "fischerd3old" not in name:
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
+    return fischer_d3_old(coord, element_list)

@@ -298,6 +298,53 @@ def g3_rsprfo():
     print("G3:", len(cfgs), "traces")
 
 
+def _read_xyz(path):
+    """Element symbols and coordinates (angstrom) of a reference test geometry (first line: charge/multiplicity or atom count)."""
+    elems, xyz = [], []
+    for line in open(path):
+        t = line.split()
+        if len(t) == 4:
+            try:
+                xyz.append([float(t[1]), float(t[2]), float(t[3])])
+                elems.append(t[0])
+            except ValueError:
+                pass
+    return elems, np.array(xyz)
+
+
+def g10_model_hessian():
+    """G10: FischerD3ApproxHessianOld.main (the `-modelhess` default) and ApproxHessian.main for organic test geometries of the
+    reference (test/*.xyz: bonds, angles, dihedrals, D3 pairs) and argon clusters (D3 pairs only)."""
+    from multioptpy.ModelHessian.fischerd3old import FischerD3ApproxHessianOld
+    try:
+        from multioptpy.ModelHessian.approx_hessian import ApproxHessian
+    except Exception as e:          # optional heavy imports of other models
+        print("ApproxHessian dispatcher not importable here:", e)
+        ApproxHessian = None
+    out = {}
+    tags = []
+    for name in ("SN2", "aldol_rxn", "claisen_rearrengment", "diels_alder_rxn", "epoxidation"):
+        elems, xyz = _read_xyz(f"/root/reference/test/{name}.xyz")
+        tags.append((name, elems, xyz / cases.BOHR2ANG))
+    for N in (7, 13):
+        tags.append((f"ar{N}", ["Ar"] * N, cases.cluster(N)))
+    # a distorted copy (different connectivity near the thresholds) and a linear triatomic
+    elems, xyz = _read_xyz("/root/reference/test/aldol_rxn.xyz")
+    rng = np.random.default_rng(10)
+    tags.append(("aldol_jitter", elems, (xyz + rng.normal(0.0, 0.08, xyz.shape)) / cases.BOHR2ANG))
+    tags.append(("co2", ["O", "C", "O"], np.array([[-1.16, 0.0, 0.0], [0.0, 0.0, 0.0], [1.16, 0.0, 0.0]]) / cases.BOHR2ANG))
+    for tag, elems, x in tags:
+        g = np.zeros_like(x)
+        with quiet():
+            H = FischerD3ApproxHessianOld().main(x.copy(), list(elems), g)
+            Hd = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="fischerd3old") if ApproxHessian else H
+        out[tag + "_x"], out[tag + "_H"], out[tag + "_Hdisp"] = x, np.array(H), np.array(Hd)
+        out[tag + "_elems"] = np.array(elems)
+    out["tags"] = np.array([t[0] for t in tags])
+    np.savez_compressed(os.path.join(HERE, "g10_model_hessian.npz"), **out)
+    print("G10:", len(tags), "geometries")
+
+
 BRENT_FUNCS = {
     "cubic": (lambda t: t ** 3 - 2 * t - 5, 2.0, 3.0),
     "cosx": (lambda t: np.cos(t) - t, 0.0, 1.0),
@@ -654,13 +701,15 @@ def g8_nebmain():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10"]
     if "g1" in which:
         g1_updates()
     if "g2" in which:
         g2_rsirfo()
     if "g3" in which:
         g3_rsprfo()
+    if "g10" in which:
+        g10_model_hessian()
     if "g4" in which:
         g4_brentq()
     if "g5" in which:

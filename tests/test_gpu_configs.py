@@ -276,3 +276,82 @@ def test_multiprocess_rccl_path_world1():
         whole.close()
     finally:
         dist.destroy_process_group()
+
+
+# ---- model Hessians on the device ------------------------------------------------------------------
+def test_model_hessian_fischerd3old_vs_reference():
+    """G10: the device's FischerD3 (old) model Hessian against the reference's own outputs (<= 1e-8; observed ~1e-15), through the
+    plugin class with the reference's signature, one geometry per call and all geometries of equal size in one batch."""
+    import os
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g10_model_hessian.npz"))
+    worst = 0.0
+    for t in z["tags"]:
+        el = [str(e) for e in z[t + "_elems"]]
+        H = ApproxHessian().main(z[t + "_x"], el, np.zeros_like(z[t + "_x"]), approx_hess_type="fischerd3old")
+        err = np.abs(H - z[t + "_H"]).max()
+        worst = max(worst, err)
+        assert err < 1e-8, (t, err)
+    a, b = "aldol_rxn", "aldol_jitter"
+    el = [str(e) for e in z[a + "_elems"]]
+    Hb = ApproxHessian().batch(np.array([z[a + "_x"], z[b + "_x"]]), el)
+    assert np.abs(Hb[0] - z[a + "_H"]).max() < 1e-8 and np.abs(Hb[1] - z[b + "_H"]).max() < 1e-8
+    with pytest.raises(NotImplementedError):
+        ApproxHessian().main(z[a + "_x"], el, None, approx_hess_type="lindh2007d3")
+    print("model Hessian: worst deviation from the reference", worst)
+
+
+def test_model_hessian_large_cluster_vs_oracle():
+    """100 and 200 atoms (argon: D3 pair terms only; a C/H chain: thousands of internal coordinates) against the oracle."""
+    from oracle import model_hessian as mh
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    x = cases.cluster(100)
+    H = ApproxHessian().main(x, ["Ar"] * 100)
+    assert np.abs(H - mh.fischer_d3_old(x, ["Ar"] * 100)).max() < 1e-10
+    # an all-trans alkane chain C30H62 (bonds / angles / dihedrals of a real molecule, 92 atoms), slightly jittered
+    rng = np.random.default_rng(3)
+    el, xyz = [], []
+    for k in range(30):
+        c = np.array([1.26 * k, 0.45 * (-1) ** k, 0.0])
+        el.append("C"); xyz.append(c)
+        for s in (-1.0, 1.0):
+            el.append("H"); xyz.append(c + np.array([0.0, 0.62 * (-1) ** k, 0.89 * s]))
+    el += ["H", "H"]
+    xyz += [xyz[0] + np.array([-0.9, 0.62, 0.0]), xyz[87] + np.array([0.9, 0.62 * (-1) ** 29, 0.0])]
+    x = (np.array(xyz) + rng.normal(0, 0.02, (len(xyz), 3))) / cases.BOHR2ANG
+    H = ApproxHessian().main(x, el)
+    ref = mh.fischer_d3_old(x, el)
+    assert np.abs(ref).max() > 0.1
+    assert np.abs(H - ref).max() < 1e-9, np.abs(H - ref).max()
+
+
+def test_band_model_hessian_resident_and_driver():
+    """Band.model_hessian writes the model Hessians of the uploaded images straight into the resident Hessians (no host round trip);
+    nebmain_steps(model_hessian=...) takes the RFO branch with them (neb.py:515-523, 794-804) and equals the same loop fed with
+    host-computed model Hessians through the tmp_hessian side channel."""
+    from multioptpy_amd.band import Band
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    from oracle import model_hessian as mh
+    I, N = 6, 13
+    X = cases.band(I, N)
+    el = ["Ar"] * N
+    E = np.zeros(I)
+    G = np.zeros((I, N, 3))
+    for i in range(I):
+        E[i], G[i] = cases.lj(X[i])
+    band = Band(I, N)
+    band.upload(X, E, G)
+    band.model_hessian(el, "fischerd3old")
+    for i in (0, 2, 5):
+        assert np.abs(band.get_hessian(i) - mh.fischer_d3_old(X[i], el)).max() < 1e-10
+    band.step(0)
+    a = band.download()
+    band.close()
+    b2 = Band(I, N)
+    Hs = ApproxHessian().batch(X, el)
+    for i in range(I):
+        b2.set_hessian(i, Hs[i])
+    b2.upload(X, E, G)
+    b2.step(0)
+    assert np.array_equal(a, b2.download())
+    b2.close()

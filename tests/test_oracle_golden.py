@@ -328,3 +328,17 @@ def test_g8_nebmain_driver(tag):
 
     worst = _check_nebmain(run, np.load(os.path.join(G, "g8_nebmain.npz")), tag, 1e-9)
     print("nebmain", tag, "worst optimizer-output deviation", worst)
+
+
+def test_g10_model_hessian_oracle_vs_reference():
+    """G10: FischerD3ApproxHessianOld.main / ApproxHessian.main of the reference (organic test geometries, argon clusters, a
+    distorted geometry, linear CO2) against the oracle's restatement."""
+    from oracle import model_hessian as mh
+    z = np.load(os.path.join(G, "g10_model_hessian.npz"))
+    for t in z["tags"]:
+        el = [str(e) for e in z[t + "_elems"]]
+        H = mh.approx_hessian(z[t + "_x"], el, None, "fischerd3old")
+        assert np.abs(H - z[t + "_H"]).max() < 1e-13, t
+        assert np.array_equal(z[t + "_H"], z[t + "_Hdisp"]), t
+    with pytest.raises(NotImplementedError):
+        mh.approx_hessian(z["co2_x"], ["O", "C", "O"], None, "lindh2007d3")
