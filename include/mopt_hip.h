@@ -57,6 +57,9 @@ int mopt_ctx_create(int device, mopt_ctx **out);
 int mopt_ctx_destroy(mopt_ctx *ctx);
 const char *mopt_last_error(const mopt_ctx *ctx);
 int mopt_ctx_sync(mopt_ctx *ctx);
+/* test hook: `blocks` workgroups holding `lds_bytes` of LDS each stay resident for about `ms` milliseconds on a stream of their
+ * own (a co-tenant for the persistent kernels of the eigen-solver); returns immediately. */
+int mopt_debug_occupy(mopt_ctx *ctx, double ms, int lds_bytes, int blocks);
 /* milliseconds spent in the named kernel family since the last reset, measured with HIP
  * events on the ctx stream when timing is enabled (bench.py roofline leg). */
 int mopt_ctx_timing(mopt_ctx *ctx, int enable);
@@ -288,6 +291,14 @@ int mopt_band_download(mopt_band *band, double *newX_angstrom, double *F, double
  * optimizer instances (optimize_num == 0) and may be NULL otherwise.  Copies are stream-ordered on the ctx. */
 int mopt_band_upload_dev(mopt_band *band, const double *dX, const double *dE, const double *dG, const double *E_host);
 int mopt_band_download_dev(mopt_band *band, double *d_newX_angstrom);
+
+/* ---- bias potentials ------------------------------------------------------------------------
+ * AFIR (multioptpy/Potential/AFIR_potential.py:19-54): E = alpha A / B over the atom pairs of two fragments; the reference gets
+ * its gradient and Hessian from torch autograd on the CPU every step (Potential/potential.py:127-152), here they are analytic
+ * kernels.  X: N x 3 (bohr); cov: N covalent radii (bohr); frag1 / frag2: 0-based atom indices (disjoint); alpha in hartree/bohr
+ * (AFIR_potential.py:34-37 from gamma).  Out: E (1), grad (N x 3), H (3N x 3N). */
+int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *cov, int n1, const int *frag1, int n2, const int *frag2, double alpha,
+              double *E, double *grad, double *H);
 
 /* ---- model Hessians ----------------------------------------------------------------
  * ApproxHessian.main (multioptpy/ModelHessian/approx_hessian.py:30-112) dispatches by name; on the device:

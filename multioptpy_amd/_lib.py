@@ -32,6 +32,8 @@ def _proto(lib):
     lib.mopt_last_error.argtypes = [vp]
     lib.mopt_last_error.restype = C.c_char_p
     lib.mopt_ctx_sync.argtypes = [vp]
+    if hasattr(lib, "mopt_debug_occupy"):
+        lib.mopt_debug_occupy.argtypes = [vp, C.c_double, C.c_int, C.c_int]
     lib.mopt_ctx_timing.argtypes = [vp, C.c_int]
     lib.mopt_ctx_timing_read.argtypes = [vp, C.c_char_p, DP, C.POINTER(C.c_int64)]
     lib.mopt_hess_update.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, DP, DP, DP]
@@ -64,6 +66,8 @@ def _proto(lib):
         lib.mopt_band_download.argtypes = [vp, DP, DP, DP]
         lib.mopt_band_upload_dev.argtypes = [vp, vp, vp, vp, DP]
         lib.mopt_band_download_dev.argtypes = [vp, vp]
+    if hasattr(lib, "mopt_afir"):
+        lib.mopt_afir.argtypes = [vp, C.c_int, DP, DP, C.c_int, IP, C.c_int, IP, C.c_double, DP, DP, DP]
     if hasattr(lib, "mopt_model_hessian"):
         lib.mopt_model_hessian.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, C.c_int, DP]
         lib.mopt_band_model_hessian.argtypes = [vp, C.c_int, DP, DP]

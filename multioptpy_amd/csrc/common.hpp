@@ -129,6 +129,7 @@ struct mopt_ctx {
     std::map<std::string, mopt_timer> timers;
     int lds_limit = 65536;
     int num_cu = 256;
+    bool tri_no_persist = false;             // eigen-solver: take the launch-per-step tridiagonalisation (retry after a hand-off time-out)
     // generic scratch arena (grow-only)
     void *arena = nullptr;
     size_t arena_bytes = 0;

@@ -319,7 +319,10 @@ __device__ __forceinline__ u64 ll_ld_s(const u64 *p, bool local) {
     return local ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double ll_val(u64 a, u64 c) { return __longlong_as_double((long long)((a & 0xffffffffull) | (c << 32))); }
-constexpr unsigned LL_SPIN_LIMIT = 2000000u;
+// a member that is not resident yet (CUs held by another kernel) starts when that kernel ends: the others wait for it up to a few
+// seconds (each spin sleeps 64 clocks and re-issues its loads), then give up with TRI_FAIL_TIMEOUT in the matrix' failure word
+constexpr unsigned LL_SPIN_LIMIT = 40000000u;
+constexpr int TRI_FAIL_TIMEOUT = 1 << 16;
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for the fabric
 // acknowledgement of every write-through store still in flight (1-2 us each step here); the exchange words need no such
 // ordering because each carries its own tag.
@@ -528,7 +531,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
     }
     if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; q[5] = t_p1; q[6] = t_p2; }
-    if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
+    if (tid == 0 && s_fail) atomicAdd(&fail_[b], TRI_FAIL_TIMEOUT);      // (every s_fail of this kernel is a hand-off that timed out)
     // D[n-1]: owner of the last row
     {
         const int gi_last = n - 1;
@@ -919,7 +922,7 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
     }
     if (prof && tid == n - 1) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_main; q[3] = t_loop; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
     __syncthreads();
-    if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
+    if (tid == 0 && s_fail) atomicAdd(&fail_[b], TRI_FAIL_TIMEOUT);      // (every s_fail of this kernel is a hand-off that timed out)
     {
         const int gi_last = n - 1;
         const int c = gi_last / TRI_RC;
@@ -1292,7 +1295,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     }
     if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = 0; q[3] = t_main; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
     __syncthreads();
-    if (tid == 0 && s_fail) atomicAdd(&fail_[b], 1);
+    if (tid == 0 && s_fail) atomicAdd(&fail_[b], TRI_FAIL_TIMEOUT);      // (every s_fail of this kernel is a hand-off that timed out)
     {
         const int gi_last = n - 1;
         const int c = gi_last / TRI_RC;
@@ -1972,12 +1975,27 @@ __global__ void __launch_bounds__(1024) k_tri_sort(int n, int npow2, const doubl
         }
         W[(size_t)b * n + rank] = ki; perm[(size_t)b * n + rank] = i;
     }
-    if (threadIdx.x == 0) { info[2 * b] = 0; info[2 * b + 1] = bad | (fail_[b] ? 4 : 0); }
+    // info word: 1 non-finite eigenvalues, 4 the solver failed for this matrix, 8 (with 4) the failure was a hand-off time-out of the
+    // persistent tridiagonalisation (GPU shared with a long-running kernel), not a numerical one
+    if (threadIdx.x == 0) { const int f = fail_[b]; info[2 * b] = 0; info[2 * b + 1] = bad | (f ? 4 : 0) | (f >= TRI_FAIL_TIMEOUT ? 8 : 0); }
 }
 
 }  // namespace mopt
 
 static int g_tri_attr = 0, g_tri_attr2 = 0;
+// Developer switches are read from the environment once per process and name (a launch used to call getenv a dozen times).
+#include <map>
+#include <mutex>
+static const char *tri_env(const char *name) {
+    static std::map<std::string, const char *> cache;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(name);
+    if (it != cache.end()) return it->second;
+    const char *v = ::getenv(name);
+    cache.emplace(name, v);
+    return v;
+}
 // back-transformation kernels: k_backtrans.hip
 bool mopt_bt_use_mfma(int n);
 int mopt_launch_bt_larft(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_A, const double *d_TAU, double *d_T);
@@ -1998,29 +2016,30 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
         g_tri_attr = 1;
     }
-    const bool multi = !(getenv("MOPT_TRI_SINGLE")) && n >= 32;
+    const bool multi = !(tri_env("MOPT_TRI_SINGLE")) && n >= 32;
+    const bool no_persist = ctx->tri_no_persist || tri_env("MOPT_TRI_NOPERSIST");
     MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
     // persistent LDS-resident variant: G workgroups per matrix with rows_cap * n doubles of LDS each
     int G = 8;
     const int cols = ((n + 63) / 64) * 64;
     int RG = 1024 / cols;
-    if (getenv("MOPT_TRI_RG")) RG = atoi(getenv("MOPT_TRI_RG"));
+    if (tri_env("MOPT_TRI_RG")) RG = atoi(tri_env("MOPT_TRI_RG"));
     if (RG < 1) RG = 1;
     if (RG > 4) RG = 4;
     auto rows_for = [&](int G_) { const int nch = (n + TRI_RC - 1) / TRI_RC; return ((nch + G_ - 1) / G_) * TRI_RC; };
     auto lds_for = [&](int G_) { return ((size_t)rows_for(G_) * n + (size_t)(3 + RG) * n) * 8; };
     while (G < 256 && lds_for(G) > (size_t)ctx->lds_limit - 4096) G *= 2;
-    const bool persist = multi && getenv("MOPT_TRI_PERSIST1") && !getenv("MOPT_TRI_NOPERSIST") && lds_for(G) <= (size_t)ctx->lds_limit - 4096 &&
+    const bool persist = multi && tri_env("MOPT_TRI_PERSIST1") && !no_persist && lds_for(G) <= (size_t)ctx->lds_limit - 4096 &&
                          G <= ctx->num_cu && n <= 1024 && 4 * G + 4 <= n;
     // row-per-wave variant (k_tri_persist2): 16 waves, accp[16][n]
-    int G2 = getenv("MOPT_TRI_G") ? atoi(getenv("MOPT_TRI_G")) : 8;
-    const bool want3 = !(getenv("MOPT_TRI_P3") && atoi(getenv("MOPT_TRI_P3")) == 0);      // row-dot variant k_tri_persist3 (default)
+    int G2 = tri_env("MOPT_TRI_G") ? atoi(tri_env("MOPT_TRI_G")) : 8;
+    const bool want3 = !(tri_env("MOPT_TRI_P3") && atoi(tri_env("MOPT_TRI_P3")) == 0);      // row-dot variant k_tri_persist3 (default)
     auto cht_for = [&]() { const int ch = (n + 63) / 64; return ch <= 6 ? ch : ch <= 8 ? 8 : ch <= 10 ? 10 : ch <= 12 ? 12 : 16; };
     auto lds2_for = [&](int G_) {
         if (want3) return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)5 * 64 * cht_for()) * 8;      // rows + v[3], w[2]
         return ((size_t)rows_for(G_) * (((n + 63) / 64) * 64) + (size_t)(5 + 16) * n) * 8;                          // rows + v, w, v', sums, accp[16]
     };
-    const bool g_forced = getenv("MOPT_TRI_G") != nullptr;      // experiment: register-resident rows with a forced group size
+    const bool g_forced = tri_env("MOPT_TRI_G") != nullptr;      // experiment: register-resident rows with a forced group size
     while (!g_forced && G2 < 256 && lds2_for(G2) > (size_t)ctx->lds_limit - 4096) G2 *= 2;
     // More workgroups per matrix when CUs are idle (few matrices per GPU) did not pay for k_tri_persist2, whose exchange grows with
     // G: measured at n = 300 with 4-16 matrices, G = 8 / 16 / 32 -> poll 1.9 / 2.8 / 4.5 us per step against 1.9 / 1.5 / 1.3 us for
@@ -2028,7 +2047,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     {
         // k_tri_persist3 exchanges n values per step whatever G is, so idle CUs do pay there: n = 300, 4 or 8 matrices (a band
         // sharded over 8 or 4 GPUs): G = 8 / 16 / 32 -> 0.614 / 0.602 / 0.555 ms.
-        const int gmax = getenv("MOPT_TRI_GMAX") ? atoi(getenv("MOPT_TRI_GMAX")) : (want3 ? ctx->num_cu / 8 : 8);
+        const int gmax = tri_env("MOPT_TRI_GMAX") ? atoi(tri_env("MOPT_TRI_GMAX")) : (want3 ? ctx->num_cu / 8 : 8);
         while (!g_forced && 2 * G2 <= gmax && 2 * G2 * batch <= ctx->num_cu && 4 * (2 * G2) + 4 <= n && rows_for(2 * G2) >= TRI_RC) G2 *= 2;
     }
     // Large matrices (n > 384: 8 or 10 column chunks): the row tile of a lane does not fit the 128 VGPRs of a 16-wave workgroup
@@ -2036,7 +2055,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     // launch.  An 8-wave workgroup (256 VGPRs per lane) keeps up to 50 doubles per lane: n = 600 on 16 workgroups per matrix,
     // 16 matrices per launch, rows in registers.
     int tr8 = 0;
-    if (want3 && !g_forced && !getenv("MOPT_TRI_NOREG") && !getenv("MOPT_TRI_NOW8") && (n + 63) / 64 >= 7 && (n + 63) / 64 <= 10) {
+    if (want3 && !g_forced && !tri_env("MOPT_TRI_NOREG") && !tri_env("MOPT_TRI_NOW8") && (n + 63) / 64 >= 7 && (n + 63) / 64 <= 10) {
         for (int g8 = 8; g8 <= ctx->num_cu / 8; g8 *= 2) {
             const int t8 = (rows_for(g8) + 7) / 8;
             if (t8 >= 4 && t8 <= 5 && 4 * g8 + 5 <= n) { G2 = g8; tr8 = t8; break; }
@@ -2044,9 +2063,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
     }
     // (the members of a matrix are placed on ONE XCD: a group cannot be larger than its num_cu / 8 compute units)
-    bool persist2 = multi && !getenv("MOPT_TRI_NOPERSIST") && !getenv("MOPT_TRI_PERSIST1") && (g_forced || tr8 > 0 || lds2_for(G2) <= (size_t)ctx->lds_limit - 4096) &&
+    bool persist2 = multi && !no_persist && !tri_env("MOPT_TRI_PERSIST1") && (g_forced || tr8 > 0 || lds2_for(G2) <= (size_t)ctx->lds_limit - 4096) &&
                     G2 <= ctx->num_cu / 8 && n <= 1024 && 4 * G2 + 5 <= n;
-    if (persist2 && !getenv("MOPT_TRI_FORCEPERSIST")) {
+    if (persist2 && !tri_env("MOPT_TRI_FORCEPERSIST")) {
         // Persistent kernel or one launch per Householder step?  Rough costs from the measurements in DESIGN.md section 5:
         // persistent: (4 + G/4) us per step and per group of num_cu/G matrices (6.2 us at G = 8; the exchange grows with G);
         // stepwise: all matrices at once, max(10 us, 40 % of the batch's bytes at 2.3 TB/s) per step (12 us at 32 x 300^2,
@@ -2070,7 +2089,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         size_t lds_use = ((size_t)rows * (((n + 63) / 64) * 64) + (size_t)5 * 64 * cht) * 8;
 #define P3(C, T) ((const void *)k_tri_persist3<C, T>)
 #define P3T(C) (tr == 1 ? P3(C, 1) : tr == 2 ? P3(C, 2) : P3(C, 3))
-        if (!getenv("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
+        if (!tri_env("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
             switch (ch <= 6 ? ch : 8) {
                 case 2: fn = P3T(2); break;
                 case 3: fn = P3T(3); break;
@@ -2096,12 +2115,19 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
 #undef P3T
 #undef P3
         MOPT_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+        {
+            // every workgroup of a launch must be able to be resident at once: one per CU, so the kernel has to fit a CU at all
+            // (registers, LDS); CUs held by other kernels delay members -- the hand-off waits for them, see LL_SPIN_LIMIT
+            int occ = 0;
+            MOPT_HIP_TRY(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nthreads, lds_use));
+            if (occ < 1) { ctx->err = "k_tri_persist3 does not fit a compute unit with this configuration"; return MOPT_E_DEVICE; }
+        }
         long long *d_prof = nullptr;
-        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
+        if (tri_env("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
         const size_t xwords = (size_t)8 * n + G;               // p vectors, pivot rows (two buffers each, two tagged words per value), XCC ids
         MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
-        int try_local = getenv("MOPT_TRI_NOLOCAL") ? 0 : 1;
+        int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;
         for (int b0 = 0; b0 < batch; b0 += per) {
             const int nb_ = (batch - b0 < per) ? batch - b0 : per;
             int per_x = (nb_ + 7) / 8;                          // matrices per XCD
@@ -2137,8 +2163,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         // register-resident rows when the tile per lane is small enough: TR rows x CH chunks <= 16 doubles
         const int tr = (rows_for(G2) + 15) / 16;
         size_t lds_use = lds2_for(G2);
-        if (getenv("MOPT_TRI_G") && ch == 5 && tr == 5) { fn = (const void *)k_tri_persist2<5, 5>; lds_use = (size_t)(5 + 16) * n * 8; }
-        else if (!getenv("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
+        if (tri_env("MOPT_TRI_G") && ch == 5 && tr == 5) { fn = (const void *)k_tri_persist2<5, 5>; lds_use = (size_t)(5 + 16) * n * 8; }
+        else if (!tri_env("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
             const int chs = ch <= 6 ? ch : 8;
 #define P3(C, T) ((const void *)k_tri_persist2<C, T>)
 #define P3T(C) (tr == 1 ? P3(C, 1) : tr == 2 ? P3(C, 2) : P3(C, 3))
@@ -2159,11 +2185,11 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const int G = G2;
         int rows = rows_for(G);
         long long *d_prof = nullptr;
-        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
+        if (tri_env("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
         const size_t xwords = ((size_t)4 * G + 4) * n + G;     // partial vectors, pivot rows, XCC ids
         MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
-        int try_local = getenv("MOPT_TRI_NOLOCAL") ? 0 : 1;   // XCD-local (sc0) stores when the run-time placement check allows
+        int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;   // XCD-local (sc0) stores when the run-time placement check allows
         for (int b0 = 0; b0 < batch; b0 += per) {
             const int nb_ = (batch - b0 < per) ? batch - b0 : per;
             int per_x = (nb_ + 7) / 8;                          // matrices per XCD
@@ -2196,7 +2222,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
         const int rows = rows_for(G);
         long long *d_prof = nullptr;
-        if (getenv("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
+        if (tri_env("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
         // exchange words live at the head of each matrix' slot of d_Vt (free until k_tri_invit): (4 G + 4) n 64-bit words <= n^2
         const size_t xwords = ((size_t)4 * G + 4) * n;
@@ -2228,7 +2254,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         hipLaunchKernelGGL(k_tri_last, dim3(batch), dim3(64), 0, ctx->stream, n, d_A, d_D);
     } else {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
-        hipLaunchKernelGGL(k_tridiag, dim3(batch), dim3(1024), (size_t)19 * n * 8, ctx->stream, n, getenv("MOPT_TRI_DBG") ? atoi(getenv("MOPT_TRI_DBG")) : 0, d_A, d_D, d_E, d_TAU);
+        hipLaunchKernelGGL(k_tridiag, dim3(batch), dim3(1024), (size_t)19 * n * 8, ctx->stream, n, tri_env("MOPT_TRI_DBG") ? atoi(tri_env("MOPT_TRI_DBG")) : 0, d_A, d_D, d_E, d_TAU);
     }
     // Blocked back-transformation on the matrix cores (the eigenvectors of a wave live in registers, 4 * ceil(n / 16) doubles per
     // lane: up to n = 384 without spilling).  Its T factors depend on the reflectors only, so k_tri_larft runs on the side
@@ -2244,7 +2270,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));
     }
     // divide and conquer (k_dc.hip) for matrices with an unreduced block of more than dc_min rows; MOPT_TRI_DC=0 switches it off
-    const int dc_min = (getenv("MOPT_TRI_DC") && atoi(getenv("MOPT_TRI_DC")) == 0) ? 0 : (getenv("MOPT_TRI_DCMIN") ? atoi(getenv("MOPT_TRI_DCMIN")) : TRI_SMALL);
+    const int dc_min = (tri_env("MOPT_TRI_DC") && atoi(tri_env("MOPT_TRI_DC")) == 0) ? 0 : (tri_env("MOPT_TRI_DCMIN") ? atoi(tri_env("MOPT_TRI_DCMIN")) : TRI_SMALL);
     int *d_dcflag = nullptr;
     if (dc_min > 0 && n > dc_min) {
         const size_t need = 256 + mopt_dc_scratch_bytes(n, batch) + (size_t)batch * 4;
@@ -2257,7 +2283,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
         d_dcflag = (int *)((char *)ctx->arena + 256 + mopt_dc_scratch_bytes(n, batch));
     }
-    int small_max = getenv("MOPT_TRI_SMALL") ? atoi(getenv("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
+    int small_max = tri_env("MOPT_TRI_SMALL") ? atoi(tri_env("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
     if (small_max > TRI_SMALL) small_max = TRI_SMALL;
     if (small_max < 0) small_max = 0;
     if (d_dcflag) {
@@ -2302,9 +2328,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const size_t perwave = ((size_t)5 * n + (n + 1) / 2 + 2) * 8;
         // dstein performs EXTRA = 2 further solves once the growth criterion is met; one is enough here (orthogonality and
         // residuals unchanged at the 1e-14 level on every parity matrix, 0 is not: 1e-11), MOPT_INVIT_EXTRA overrides
-        const int extra = getenv("MOPT_INVIT_EXTRA") ? atoi(getenv("MOPT_INVIT_EXTRA")) : 1;
+        const int extra = tri_env("MOPT_INVIT_EXTRA") ? atoi(tri_env("MOPT_INVIT_EXTRA")) : 1;
         hipLaunchKernelGGL(k_tri_invit, dim3(n, batch), dim3(64), perwave, ctx->stream, n, d_D, d_E, d_WT, d_bstart, d_bend, d_cstart,
-                           d_ncl, d_onenrm, d_Vt, d_fail, extra, getenv("MOPT_INVIT_DBG") ? 1 : 0, small_max);
+                           d_ncl, d_onenrm, d_Vt, d_fail, extra, tri_env("MOPT_INVIT_DBG") ? 1 : 0, small_max);
         // work-list driven (k_tri_clusters): lw workgroups per matrix walk its list
         int lw = 2048 / batch;
         lw = lw < 8 ? 8 : (lw > n ? n : lw);
@@ -2322,7 +2348,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     }
     if (bt_mfma) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the T factors (side stream)
     { const int rc = mopt_launch_backtrans(ctx, n, batch, d_A, d_TAU, bt_T, d_Vt, d_bend, bt_mfma); if (rc != MOPT_OK) return rc; }
-    if (getenv("MOPT_TRI_INJECT_FAIL")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 1, sizeof(int), ctx->stream));   // test hook: matrix 0 fails
+    if (tri_env("MOPT_TRI_INJECT_FAIL")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 1, sizeof(int), ctx->stream));   // test hook: matrix 0 fails
+    if (tri_env("MOPT_TRI_INJECT_TIMEOUT") && !ctx->tri_no_persist)       // test hook: matrix 0 reports a hand-off time-out on the persistent route
+        MOPT_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_fail, TRI_FAIL_TIMEOUT, 1, ctx->stream));
     {
         mopt_scope sc(ctx, "eigh_final", 1);
         int np2 = 1;

@@ -79,6 +79,27 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     return MOPT_OK;
 }
 
+namespace { __global__ void __launch_bounds__(256) k_debug_occupy(long long ticks, double *sink) {
+    extern __shared__ double hog[];
+    const long long t0 = wall_clock64();
+    double a = 0.0;
+    while (wall_clock64() - t0 < ticks) { hog[threadIdx.x] = a; a += hog[(threadIdx.x + 1) & 255] * 1e-30 + 1.0; __builtin_amdgcn_s_sleep(8); }
+    if (a < 0.0) sink[0] = a;
+} }
+
+// Test hook: keep `blocks` workgroups with `lds_bytes` of LDS each resident for about `ms` milliseconds on a stream of their own
+// (a co-tenant for the persistent kernels); returns at once.
+extern "C" int mopt_debug_occupy(mopt_ctx *ctx, double ms, int lds_bytes, int blocks) {
+    if (!ctx || blocks < 1 || lds_bytes < 2048) return MOPT_E_ARG;
+    hipSetDevice(ctx->device);
+    static hipStream_t st = nullptr;
+    if (!st) MOPT_HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_debug_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+    hipLaunchKernelGGL(k_debug_occupy, dim3(blocks), dim3(256), (size_t)lds_bytes, st, (long long)(ms * 1e5), (double *)nullptr);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
 extern "C" const char *mopt_last_error(const mopt_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 extern "C" int mopt_ctx_sync(mopt_ctx *ctx) {
@@ -174,6 +195,28 @@ extern "C" int mopt_project_trrot_hess(mopt_ctx *ctx, int n, int batch, const do
     return MOPT_OK;
 }
 
+extern "C" int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *cov, int n1, const int *frag1, int n2, const int *frag2, double alpha,
+                         double *E, double *grad, double *H) {
+    if (!ctx) return MOPT_E_ARG;
+    if (bad_dims(ctx, 3 * N, 1) || N < 2 || n1 < 1 || n2 < 1 || !X || !cov || !frag1 || !frag2 || !E || !grad || !H) return MOPT_E_ARG;
+    for (int a = 0; a < n1; ++a) if (frag1[a] < 0 || frag1[a] >= N) { ctx->err = "mopt_afir: fragment atom out of range (0-based indices)"; return MOPT_E_ARG; }
+    for (int b = 0; b < n2; ++b) {
+        if (frag2[b] < 0 || frag2[b] >= N) { ctx->err = "mopt_afir: fragment atom out of range (0-based indices)"; return MOPT_E_ARG; }
+        for (int a = 0; a < n1; ++a) if (frag1[a] == frag2[b]) { ctx->err = "mopt_afir: the fragments share an atom"; return MOPT_E_ARG; }
+    }
+    hipSetDevice(ctx->device);
+    const int n = 3 * N;
+    DBuf dX, dC, dF1, dF2, dW, dE, dG, dH;
+    TRY(dX.alloc(ctx, (size_t)n * 8)); TRY(dC.alloc(ctx, (size_t)N * 8)); TRY(dF1.alloc(ctx, (size_t)n1 * 4)); TRY(dF2.alloc(ctx, (size_t)n2 * 4));
+    TRY(dW.alloc(ctx, (size_t)(2 + 6 * N) * 8)); TRY(dE.alloc(ctx, 8)); TRY(dG.alloc(ctx, (size_t)n * 8)); TRY(dH.alloc(ctx, (size_t)n * n * 8));
+    H2D(ctx, dX.p, X, (size_t)n * 8); H2D(ctx, dC.p, cov, (size_t)N * 8); H2D(ctx, dF1.p, frag1, (size_t)n1 * 4); H2D(ctx, dF2.p, frag2, (size_t)n2 * 4);
+    TRY(mopt_launch_afir(ctx, N, dX.as<double>(), dC.as<double>(), n1, dF1.as<int>(), n2, dF2.as<int>(), alpha, dW.as<double>(), dE.as<double>(),
+                         dG.as<double>(), dH.as<double>()));
+    D2H(ctx, E, dE.p, 8); D2H(ctx, grad, dG.p, (size_t)n * 8); D2H(ctx, H, dH.p, (size_t)n * n * 8);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
 extern "C" int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H) {
     if (!ctx) return MOPT_E_ARG;
     if (kind != MOPT_MODEL_FISCHERD3OLD) { ctx->err = "mopt_model_hessian: unknown model"; return MOPT_E_ARG; }
@@ -212,27 +255,45 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     TRY(dA.alloc(ctx, nn)); TRY(dG.alloc(ctx, nn + (size_t)batch * MOPT_TRI_T_DOUBLES(n) * sizeof(double))); TRY(dVt.alloc(ctx, nn)); TRY(dV.alloc(ctx, nn));
     TRY(dsig.alloc(ctx, batch * sizeof(double))); TRY(drot.alloc(ctx, (size_t)batch * (JAC_MAX_SWEEPS + 1) * sizeof(int)));
     TRY(dW.alloc(ctx, nv)); TRY(dperm.alloc(ctx, (size_t)batch * n * sizeof(int))); TRY(dinfo.alloc(ctx, (size_t)batch * 2 * sizeof(int)));
-    H2D(ctx, dA.p, A, nn);
-    if (mopt_eigh_algo(n) == 1) {
-        DBuf dsc, dsi;
-        const size_t nvi = (size_t)batch * n;
-        TRY(dsc.alloc(ctx, 5 * nvi * 8)); TRY(dsi.alloc(ctx, (4 * nvi + 3 * batch) * 4));
-        double *sc = dsc.as<double>();
-        int *si = dsi.as<int>();
-        TRY(mopt_launch_eigh_tridiag(ctx, n, batch, dA.as<double>(), dVt.as<double>(), sc, sc + nvi, sc + 2 * nvi, sc + 3 * nvi, sc + 4 * nvi,
-                                     si, si + nvi, si + 2 * nvi, si + 4 * nvi, si + 4 * nvi + 2 * batch, dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), dG.as<double>()));
+    std::vector<int> info(2 * batch);
+    // Two attempts at most: when the persistent tridiagonalisation gave up on a hand-off (its workgroups were not all resident in
+    // time: the GPU is shared with a long-running kernel), the matrices are solved again with one launch per Householder step,
+    // which needs no co-residency -- a busy GPU is not a numerical failure.
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        H2D(ctx, dA.p, A, nn);
+        if (mopt_eigh_algo(n) == 1) {
+            DBuf dsc, dsi;
+            const size_t nvi = (size_t)batch * n;
+            TRY(dsc.alloc(ctx, 5 * nvi * 8)); TRY(dsi.alloc(ctx, (4 * nvi + 3 * batch) * 4));
+            double *sc = dsc.as<double>();
+            int *si = dsi.as<int>();
+            const bool saved = ctx->tri_no_persist;
+            if (attempt == 1) ctx->tri_no_persist = true;
+            const int rc = mopt_launch_eigh_tridiag(ctx, n, batch, dA.as<double>(), dVt.as<double>(), sc, sc + nvi, sc + 2 * nvi, sc + 3 * nvi, sc + 4 * nvi,
+                                                    si, si + nvi, si + 2 * nvi, si + 4 * nvi, si + 4 * nvi + 2 * batch, dW.as<double>(), dperm.as<int>(),
+                                                    dinfo.as<int>(), dG.as<double>());
+            ctx->tri_no_persist = saved;
+            if (rc != MOPT_OK) return rc;
+            MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        } else
+        TRY(mopt_launch_eigh(ctx, n, batch, dA.as<double>(), dsig.as<double>(), dG.as<double>(), dVt.as<double>(), drot.as<int>(),
+                             dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), MOPT_DEFAULT_SWEEPS, false));
+        D2H(ctx, info.data(), dinfo.p, (size_t)batch * 2 * sizeof(int));
         MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    } else
-    TRY(mopt_launch_eigh(ctx, n, batch, dA.as<double>(), dsig.as<double>(), dG.as<double>(), dVt.as<double>(), drot.as<int>(),
-                         dW.as<double>(), dperm.as<int>(), dinfo.as<int>(), MOPT_DEFAULT_SWEEPS, false));
+        bool timed_out = false;
+        for (int b = 0; b < batch; ++b) timed_out = timed_out || (info[2 * b + 1] & 8);
+        if (!timed_out) break;
+    }
     TRY(mopt_launch_eig_gather(ctx, n, batch, dVt.as<double>(), dperm.as<int>(), dV.as<double>()));
     D2H(ctx, W, dW.p, nv); D2H(ctx, V, dV.p, nn);
-    std::vector<int> info(2 * batch);
-    D2H(ctx, info.data(), dinfo.p, (size_t)batch * 2 * sizeof(int));
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (sweeps_out) for (int b = 0; b < batch; ++b) sweeps_out[b] = info[2 * b];
     for (int b = 0; b < batch; ++b)
-        if (info[2 * b + 1] & 4) { ctx->err = "mopt_eigh: the reduction-route eigen-solver failed (inverse iteration or workgroup hand-off)"; return MOPT_E_NUMERIC; }
+        if (info[2 * b + 1] & 4) {
+            ctx->err = (info[2 * b + 1] & 8) ? "mopt_eigh: the workgroup hand-off of the tridiagonalisation timed out (GPU shared with a long-running kernel)"
+                                             : "mopt_eigh: the reduction-route eigen-solver failed (inverse iteration / secular equation did not converge)";
+            return MOPT_E_NUMERIC;
+        }
     return MOPT_OK;
 }
 

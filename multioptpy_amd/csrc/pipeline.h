@@ -55,6 +55,9 @@ int mopt_launch_project_grad(mopt_ctx *ctx, int n, int batch, const double *d_g,
                              bool side_stream = false);
 int mopt_launch_matvec(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_v, double *d_out);
 int mopt_launch_sym_add(mopt_ctx *ctx, int n, int batch, const double *d_H, const double *d_Bias, double *d_A);
+// AFIR bias potential (k_afir.hip): energy, gradient, Hessian on the device; d_work: 2 + 6 N doubles
+int mopt_launch_afir(mopt_ctx *ctx, int N, const double *d_x, const double *d_cov, int n1, const int *d_f1, int n2, const int *d_f2, double alpha,
+                     double *d_work, double *d_E, double *d_grad, double *d_H);
 // FischerD3ApproxHessianOld.main for a batch of geometries (k_modelhess.hip); d3 is a HOST array {s6, s8, a1, a2}
 int mopt_launch_model_hessian(mopt_ctx *ctx, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
                               double *d_W, double *d_A, bool project);

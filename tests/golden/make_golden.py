@@ -345,6 +345,36 @@ def g10_model_hessian():
     print("G10:", len(tags), "geometries")
 
 
+def g11_afir():
+    """G11: AFIRPotential.calc_energy with its gradient and Hessian as the reference obtains them (torch.func.jacrev / hessian,
+    Potential/potential.py:127-152) for several geometries, fragment pairs and gamma values (kJ/mol, both signs and zero)."""
+    import torch
+    from multioptpy.Potential.AFIR_potential import AFIRPotential
+    out = {}
+    cases_ = []
+    elems, xyz = _read_xyz("/root/reference/test/aldol_rxn.xyz")
+    x = xyz / cases.BOHR2ANG
+    cases_.append(("aldol_a", elems, x, [1, 2, 3], [5, 6, 7, 8], 100.0))
+    cases_.append(("aldol_b", elems, x, [1], [11], -50.0))
+    cases_.append(("aldol_c", elems, x, [4, 5], [9, 10, 11], 0.0))
+    elems2, xyz2 = _read_xyz("/root/reference/test/diels_alder_rxn.xyz")
+    cases_.append(("da", elems2, xyz2 / cases.BOHR2ANG, list(range(1, 11)), list(range(11, 23)), 250.0))
+    cases_.append(("ar13", ["Ar"] * 13, cases.cluster(13), [1, 2, 3, 4, 5, 6], [7, 8, 9, 10, 11, 12, 13], 30.0))
+    for tag, el, xb, f1, f2, gam in cases_:
+        pot = AFIRPotential(AFIR_gamma=gam, AFIR_Fragm_1=f1, AFIR_Fragm_2=f2, element_list=list(el))
+        g = torch.tensor(xb, dtype=torch.float64)
+        par = torch.tensor([gam], dtype=torch.float64)
+        e = pot.calc_energy(g, par)
+        grad = torch.func.jacrev(pot.calc_energy, argnums=0)(g, par)
+        hess = torch.func.hessian(pot.calc_energy, argnums=0)(g, par).reshape(3 * len(el), 3 * len(el))
+        out[tag + "_x"], out[tag + "_elems"] = xb, np.array(el)
+        out[tag + "_f1"], out[tag + "_f2"], out[tag + "_gamma"] = np.array(f1), np.array(f2), np.array(gam)
+        out[tag + "_E"], out[tag + "_g"], out[tag + "_H"] = np.array(float(e)), grad.detach().numpy(), hess.detach().numpy()
+    out["tags"] = np.array([c[0] for c in cases_])
+    np.savez_compressed(os.path.join(HERE, "g11_afir.npz"), **out)
+    print("G11:", len(cases_), "cases")
+
+
 BRENT_FUNCS = {
     "cubic": (lambda t: t ** 3 - 2 * t - 5, 2.0, 3.0),
     "cosx": (lambda t: np.cos(t) - t, 0.0, 1.0),
@@ -701,7 +731,7 @@ def g8_nebmain():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g11"]
     if "g1" in which:
         g1_updates()
     if "g2" in which:
@@ -710,6 +740,8 @@ if __name__ == "__main__":
         g3_rsprfo()
     if "g10" in which:
         g10_model_hessian()
+    if "g11" in which:
+        g11_afir()
     if "g4" in which:
         g4_brentq()
     if "g5" in which:

@@ -355,3 +355,62 @@ def test_band_model_hessian_resident_and_driver():
     b2.step(0)
     assert np.array_equal(a, b2.download())
     b2.close()
+
+
+# ---- the persistent tridiagonalisation on a shared GPU ------------------------------------------------------------------------
+def test_eigh_with_cotenant_kernel():
+    """A long LDS-heavy kernel holds half of the CUs on another stream while mopt_eigh runs (n = 300, batch 32: the persistent kernel
+    wants all 256): the members that find no CU start late, the hand-off waits for them -- the call succeeds and is correct."""
+    import ctypes as C
+    from multioptpy_amd import ops, _lib
+    rng = np.random.default_rng(77)
+    A = rng.normal(size=(32, 300, 300))
+    A = 0.5 * (A + A.transpose(0, 2, 1))
+    c = _lib.ctx()
+    _lib.check(_lib.lib().mopt_debug_occupy(c, 150.0, 140000, 128), c)
+    w, v = ops.eigh(A)
+    for b in (0, 13, 31):
+        wr = np.linalg.eigvalsh(A[b])
+        nrm = np.abs(A[b]).sum(axis=1).max()
+        assert np.abs(w[b] - wr).max() < 1e-13 * nrm
+        assert np.abs(A[b] @ v[b] - v[b] * w[b]).max() < 5e-12 * nrm
+
+
+def test_eigh_timeout_falls_back_to_stepwise():
+    """An injected hand-off time-out (MOPT_TRI_INJECT_TIMEOUT) on the persistent route: mopt_eigh solves again with one launch per
+    Householder step and returns the correct result instead of MOPT_E_NUMERIC."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, os.getcwd())
+from multioptpy_amd import ops
+rng = np.random.default_rng(5)
+A = rng.normal(size=(4, 200, 200)); A = 0.5 * (A + A.transpose(0, 2, 1))
+w, v = ops.eigh(A)
+for b in range(4):
+    wr = np.linalg.eigvalsh(A[b]); nrm = np.abs(A[b]).sum(axis=1).max()
+    assert np.abs(w[b] - wr).max() < 1e-13 * nrm, b
+    assert np.abs(A[b] @ v[b] - v[b] * w[b]).max() < 5e-12 * nrm, b
+print("ok")
+'''
+    env = dict(os.environ, MOPT_TRI_INJECT_TIMEOUT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_afir_bias_vs_reference():
+    """G11: AFIR bias energy / gradient / Hessian on the device against the reference's torch-autograd values (<= 1e-8; ~1e-16)."""
+    import os
+    from multioptpy_amd.Potential.AFIR_potential import AFIRPotential
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g11_afir.npz"))
+    for t in z["tags"]:
+        el = [str(e) for e in z[t + "_elems"]]
+        pot = AFIRPotential(AFIR_gamma=float(z[t + "_gamma"]), AFIR_Fragm_1=list(z[t + "_f1"]), AFIR_Fragm_2=list(z[t + "_f2"]), element_list=el)
+        E, g, H = pot.calc_energy_gradient_hessian(z[t + "_x"], [float(z[t + "_gamma"])])
+        assert abs(E - float(z[t + "_E"])) < 1e-10, t
+        assert np.abs(g - z[t + "_g"]).max() < 1e-10, (t, np.abs(g - z[t + "_g"]).max())
+        assert np.abs(H - z[t + "_H"]).max() < 1e-10, (t, np.abs(H - z[t + "_H"]).max())
+        assert np.abs(H - H.T).max() < 1e-14

@@ -342,3 +342,14 @@ def test_g10_model_hessian_oracle_vs_reference():
         assert np.array_equal(z[t + "_H"], z[t + "_Hdisp"]), t
     with pytest.raises(NotImplementedError):
         mh.approx_hessian(z["co2_x"], ["O", "C", "O"], None, "lindh2007d3")
+
+
+def test_g11_afir_oracle_vs_reference():
+    """G11: AFIR energy, gradient and Hessian (the reference's torch autograd outputs) against the oracle's analytic form."""
+    from oracle import afir, model_hessian as mh
+    z = np.load(os.path.join(G, "g11_afir.npz"))
+    for t in z["tags"]:
+        el = [str(e) for e in z[t + "_elems"]]
+        cov = mh.element_params(el)["cov"]
+        E, g, H = afir.afir(z[t + "_x"], cov, list(z[t + "_f1"]), list(z[t + "_f2"]), float(z[t + "_gamma"]))
+        assert abs(E - float(z[t + "_E"])) < 1e-14 and np.abs(g - z[t + "_g"]).max() < 1e-14 and np.abs(H - z[t + "_H"]).max() < 1e-14, t
