@@ -58,7 +58,7 @@ class ConvergenceChecker:
 
 def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, saddle_order=0, NSTEP=300, FC_COUNT=-1,
                   max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False, model_hessian=None,
-                  MFC_COUNT=50):
+                  MFC_COUNT=50, afir=None):
     """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy)."""
     natom = len(element_list)
     geometry = np.array(start_geometry_ang, dtype="float64") / BOHR2ANGSTROMS
@@ -99,6 +99,13 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
             Model_hess = ApproxHessian().main(geometry, element_list, np.asarray(g, dtype="float64"), model_hessian)
             calculator.Model_hess = Model_hess
         bias_hessian = np.zeros((3 * natom, 3 * natom))
+        bias_energy, bias_gradient = 0.0, np.zeros((natom, 3))
+        if afir is not None:
+            # BiasPotentialCalculation.main (Potential/potential.py:127-152) for the AFIR term (`-ma gamma fragm_1 fragm_2`): energy,
+            # gradient and Hessian of the bias from the device kernels instead of torch autograd
+            from .Potential.AFIR_potential import AFIRPotential
+            pot = AFIRPotential(AFIR_gamma=afir["gamma"], AFIR_Fragm_1=afir["fragm_1"], AFIR_Fragm_2=afir["fragm_2"], element_list=element_list)
+            bias_energy, bias_gradient, bias_hessian = pot.calc_energy_gradient_hessian(geometry, [afir["gamma"]])
         if it == 0:                                                     # _save_init_geometry (optimization.py:2206-2217)
             centre = tools.calc_center(geometry, element_list)
             pre_geometry = (geometry - centre) - centre
@@ -108,7 +115,8 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
             if it % FC_COUNT == 0 or (model_hessian is not None and it % MFC_COUNT == 0):      # optimization.py:1354-1367
                 inst.set_hessian(Model_hess)
         g_raw = copy.deepcopy(np.asarray(g, dtype="float64"))
-        B_g = copy.deepcopy(np.asarray(g, dtype="float64"))
+        B_g = copy.deepcopy(np.asarray(g, dtype="float64")) + bias_gradient
+        e = e + bias_energy                                             # B_e: the biased energy drives the trust radius (optimizer.py:740-841)
         effective_gradient = g_raw + (B_g - g_raw)
         geometry_in = geometry.copy() if record is not None else None
         new_geometry, move_vector, optimizer_instances = CMV.calc_move_vector(

@@ -414,3 +414,52 @@ def test_afir_bias_vs_reference():
         assert np.abs(g - z[t + "_g"]).max() < 1e-10, (t, np.abs(g - z[t + "_g"]).max())
         assert np.abs(H - z[t + "_H"]).max() < 1e-10, (t, np.abs(H - z[t + "_H"]).max())
         assert np.abs(H - H.T).max() < 1e-14
+
+
+def test_rsirfo_with_afir_bias_vs_oracle():
+    """The biased step (optimizer.py:546,641: hessian + bias_hessian, B_g = g + bias gradient): RSIRFO.run on the aldol geometry with the
+    model Hessian as PES curvature and an AFIR bias pushing two fragments together, HIP plugin class against the oracle (three runs)."""
+    import os
+    from multioptpy_amd.Optimizer.rsirfo import RSIRFO
+    from multioptpy_amd.Potential.AFIR_potential import AFIRPotential
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    from oracle.rsirfo import RSIRFO as OracleRSIRFO
+    from oracle import afir as oafir, model_hessian as mh
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g10_model_hessian.npz"))
+    el = [str(e) for e in z["aldol_rxn_elems"]]
+    x0 = z["aldol_rxn_x"]
+    K = ApproxHessian().main(x0, el)                      # quadratic model surface E = 1/2 (x - x0) K (x - x0) + d.(x - x0)
+    rng = np.random.default_rng(8)
+    d = 0.01 * rng.normal(size=x0.size)
+    f1, f2, gam = [1, 2, 3], [5, 6, 7, 8], 150.0
+    pot = AFIRPotential(AFIR_gamma=gam, AFIR_Fragm_1=f1, AFIR_Fragm_2=f2, element_list=el)
+    cov = mh.element_params(el)["cov"]
+
+    def surface(x):
+        dx = (x - x0).reshape(-1)
+        return 0.5 * dx @ K @ dx + d @ dx, (K @ dx + d).reshape(-1, 1)
+
+    outs = []
+    for cls, bias in ((RSIRFO, lambda x: pot.calc_energy_gradient_hessian(x, [gam])), (OracleRSIRFO, lambda x: oafir.afir(x, cov, f1, f2, gam))):
+        opt = cls(method="rsirfo_fsb", saddle_order=0)
+        x = x0.copy()
+        px = pg = pbg = None
+        pE = 0.0
+        steps = []
+        for it in range(3):
+            E, g = surface(x)
+            Eb, gb, Hb = bias(x)
+            Bg = g + gb.reshape(-1, 1)
+            opt.set_bias_hessian(np.array(Hb))
+            if it == 0:
+                opt.set_hessian(K.copy())
+                s = opt.run(x.reshape(-1, 1), Bg, [], [], E + Eb, 0.0, [], [], g, [])
+            else:
+                s = opt.run(x.reshape(-1, 1), Bg, pbg, px, E + Eb, pE, [], [], g, pg)
+            steps.append(np.asarray(s).copy())
+            px, pg, pbg, pE = x.reshape(-1, 1).copy(), g.copy(), Bg.copy(), E + Eb
+            x = (x.reshape(-1, 1) - s).reshape(-1, 3)
+        outs.append((steps, np.array(opt.hessian), opt.trust_radius))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.abs(a - b).max() < 1e-8, np.abs(a - b).max()
+    assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-8 and abs(outs[0][2] - outs[1][2]) < 1e-12
