@@ -78,6 +78,9 @@ int mopt_ctx_timing_read(mopt_ctx *ctx, const char *family, double *ms, int64_t 
  *   info      out: batch x 8 doubles {applied, s.y, s.s, y.y, s.Hs, phi2/weight, branch, 0}, may be NULL */
 int mopt_hess_update(mopt_ctx *ctx, int rule, int n, int batch, const double *H, const double *s,
                      const double *y, double *H_inplace, double *H_sym, double *info);
+/* delta-H of one rule without RSIRFO.update_hessian's guards: the return value of ModelHessianUpdate.<rule>_hessian_update
+ * (hessian_update.py:163-433) as the IRC integrators use it (IRC/lqa.py:286, IRC/hpc.py:421). */
+int mopt_hess_delta(mopt_ctx *ctx, int rule, int n, int batch, const double *H, const double *s, const double *y, double *dH);
 
 /* Calculationtools.project_out_hess_tr_and_rot_for_coord (multioptpy/Utils/calc_tools.py:249-316):
  * Hp = sym(P^T H P), P = I - sum v v^T over the Gram-Schmidt'ed translation/rotation vectors. */
@@ -291,6 +294,19 @@ int mopt_band_download(mopt_band *band, double *newX_angstrom, double *F, double
  * optimizer instances (optimize_num == 0) and may be NULL otherwise.  Copies are stream-ordered on the ctx. */
 int mopt_band_upload_dev(mopt_band *band, const double *dX, const double *dE, const double *dG, const double *E_host);
 int mopt_band_download_dev(mopt_band *band, double *d_newX_angstrom);
+
+/* ---- constraints ---------------------------------------------------------------------
+ * mopt_constraint_project_hess: ProjectOutConstrain.calc_project_out_hess (multioptpy/Constraint/constraint_condition.py:657-754):
+ *   H_out = H - P H - H P + P H P + k_hard P + k_soft P_soft,  P = Q^T Q (Q: c x n orthonormal rows = the basis of the current
+ *   constraint rows), P_soft = S^T S (S: cs x n, the orthogonalised residuals of the stored bases; cs may be 0).
+ * mopt_crsirfo_run: CRSIRFO.run (multioptpy/Optimizer/crsirfo.py:48-182) behind the SHAKE-like adjustment: arguments as
+ *   mopt_rsirfo_run (batch 1) plus U (n x m row-major, orthonormal columns spanning the null space of the constraints): Hessian
+ *   update, U^T (H + bias) U, eigen-solve and RS-I-RFO step in the subspace, step = U step_sub.  No TR/rot projection. */
+int mopt_constraint_project_hess(mopt_ctx *ctx, int n, const double *H, int c, const double *Q, int cs, const double *S, double k_hard,
+                                 double k_soft, double *H_out);
+int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
+                     const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                     const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym);
 
 /* ---- bias potentials ------------------------------------------------------------------------
  * AFIR (multioptpy/Potential/AFIR_potential.py:19-54): E = alpha A / B over the atom pairs of two fragments; the reference gets

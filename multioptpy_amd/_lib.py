@@ -37,6 +37,8 @@ def _proto(lib):
     lib.mopt_ctx_timing.argtypes = [vp, C.c_int]
     lib.mopt_ctx_timing_read.argtypes = [vp, C.c_char_p, DP, C.POINTER(C.c_int64)]
     lib.mopt_hess_update.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, DP, DP, DP]
+    if hasattr(lib, "mopt_hess_delta"):
+        lib.mopt_hess_delta.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, DP]
     lib.mopt_project_trrot_hess.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP]
     lib.mopt_project_trrot_grad.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP]
     lib.mopt_eigh.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, IP]
@@ -66,6 +68,10 @@ def _proto(lib):
         lib.mopt_band_download.argtypes = [vp, DP, DP, DP]
         lib.mopt_band_upload_dev.argtypes = [vp, vp, vp, vp, DP]
         lib.mopt_band_download_dev.argtypes = [vp, vp]
+    if hasattr(lib, "mopt_crsirfo_run"):
+        lib.mopt_constraint_project_hess.argtypes = [vp, C.c_int, DP, C.c_int, DP, C.c_int, DP, C.c_double, C.c_double, DP]
+        lib.mopt_crsirfo_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),
+                                         DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_afir"):
         lib.mopt_afir.argtypes = [vp, C.c_int, DP, DP, C.c_int, IP, C.c_int, IP, C.c_double, DP, DP, DP]
     if hasattr(lib, "mopt_model_hessian"):

@@ -1,0 +1,177 @@
+// Constraint projection of the Hessian and the constrained RS-I-RFO step.
+//   mopt_constraint_project_hess   ProjectOutConstrain.calc_project_out_hess (multioptpy/Constraint/constraint_condition.py:657-754):
+//       H_eff = H - P H - H P + P H P + k_hard P_hard + k_soft P_soft,   P = P_hard = sum q q^T over the orthonormal basis of the
+//       current constraint rows, P_soft over the orthogonalised residuals of the stored bases.  The reference forms three dense n^3
+//       products; with c = rank(P) << n the same matrix is H minus a rank-2c correction:  W1 = H Q, W2 = H^T Q, M = Q^T W1 (c x c).
+//   mopt_crsirfo_run               CRSIRFO.run (multioptpy/Optimizer/crsirfo.py:48-182) behind the SHAKE-like adjustment and the
+//       null-space basis U (both O(c n) / one LAPACK call on c x n in the host class): Hessian update, H_sub = U^T (H + bias) U on the
+//       FP64 matrix cores, symmetric eigen-solve of the (n - c) x (n - c) matrix, RS-I-RFO step in the subspace (the kernels of
+//       RSIRFO.run: same trust-radius, image-function and secular logic), step = U step_sub.  No TR/rot projection, as in the reference.
+#include <cstring>
+
+#include "pipeline.h"
+
+namespace mopt {
+
+// W1[i][a] = sum_j H[i][j] Q[a][j]      grid n, block 256 (one workgroup per row, coalesced along j)
+__global__ void __launch_bounds__(256) k_cp_w1(int n, int c, const double *__restrict__ H, const double *__restrict__ Q, double *__restrict__ W1) {
+    __shared__ double red[16];
+    const int i = blockIdx.x;
+    for (int a = 0; a < c; ++a) {
+        double s = 0.0;
+        for (int j = threadIdx.x; j < n; j += blockDim.x) s += H[(size_t)i * n + j] * Q[(size_t)a * n + j];
+        s = block_sum1(s, red);
+        if (threadIdx.x == 0) W1[(size_t)i * c + a] = s;
+    }
+}
+// W2[i][a] = sum_j H[j][i] Q[a][j]      thread per column i (coalesced along i), fixed summation order
+__global__ void __launch_bounds__(256) k_cp_w2(int n, int c, const double *__restrict__ H, const double *__restrict__ Q, double *__restrict__ W2) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (int a = 0; a < c; ++a) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) s += H[(size_t)j * n + i] * Q[(size_t)a * n + j];
+        W2[(size_t)i * c + a] = s;
+    }
+}
+// M[a][b] = sum_i Q[a][i] W1[i][b]       one workgroup
+__global__ void __launch_bounds__(256) k_cp_m(int n, int c, const double *__restrict__ Q, const double *__restrict__ W1, double *__restrict__ M) {
+    __shared__ double red[16];
+    for (int a = 0; a < c; ++a)
+        for (int b = 0; b < c; ++b) {
+            double s = 0.0;
+            for (int i = threadIdx.x; i < n; i += blockDim.x) s += Q[(size_t)a * n + i] * W1[(size_t)i * c + b];
+            s = block_sum1(s, red);
+            if (threadIdx.x == 0) M[a * c + b] = s;
+        }
+}
+// grid (ceil(n / 256), n): element (i = blockIdx.y, j)
+__global__ void __launch_bounds__(256) k_cp_apply(int n, int c, int cs, const double *__restrict__ H, const double *__restrict__ Q, const double *__restrict__ S,
+                                                  const double *__restrict__ W1, const double *__restrict__ W2, const double *__restrict__ M, double kh, double ks,
+                                                  double *__restrict__ out) {
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double ph = 0.0, hp = 0.0, php = 0.0, pp = 0.0, sp = 0.0;
+    for (int a = 0; a < c; ++a) {
+        const double qai = Q[(size_t)a * n + i], qaj = Q[(size_t)a * n + j];
+        ph += qai * W2[(size_t)j * c + a];
+        hp += W1[(size_t)i * c + a] * qaj;
+        pp += qai * qaj;
+        double t = 0.0;
+        for (int b = 0; b < c; ++b) t += M[a * c + b] * Q[(size_t)b * n + j];
+        php += qai * t;
+    }
+    for (int a = 0; a < cs; ++a) sp += S[(size_t)a * n + i] * S[(size_t)a * n + j];
+    out[(size_t)i * n + j] = H[(size_t)i * n + j] - ph - hp + php + kh * pp + ks * sp;
+}
+
+// leading m x m block of an n x n matrix, symmetrised
+__global__ void __launch_bounds__(256) k_lead_block_sym(int n, int m, const double *__restrict__ src, double *__restrict__ dst) {
+    const int i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+    if (i < m && j < m) dst[(size_t)i * m + j] = 0.5 * (src[(size_t)i * n + j] + src[(size_t)j * n + i]);
+}
+__global__ void __launch_bounds__(256) k_pad_copy(int m, int n, const double *__restrict__ src, double *__restrict__ dst) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (i < m) ? src[i] : 0.0;
+}
+
+}  // namespace mopt
+
+namespace {
+struct DB {
+    void *p = nullptr;
+    ~DB() { if (p) hipFree(p); }
+    int alloc(mopt_ctx *ctx, size_t bytes) { if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { ctx->err = "hipMalloc failed"; p = nullptr; return MOPT_E_NOMEM; } return MOPT_OK; }
+    template <class T> T *as() { return (T *)p; }
+};
+}
+#define CTRY_(x) do { int rc__ = (x); if (rc__ != MOPT_OK) return rc__; } while (0)
+#define CH2D(ctx, d, s, b) MOPT_HIP_TRY(ctx, hipMemcpyAsync(d, s, b, hipMemcpyHostToDevice, (ctx)->stream))
+#define CD2H(ctx, d, s, b) MOPT_HIP_TRY(ctx, hipMemcpyAsync(d, s, b, hipMemcpyDeviceToHost, (ctx)->stream))
+
+// Q: c x n orthonormal rows (hard wall), S: cs x n (soft wall, may be empty).  All host pointers.
+extern "C" int mopt_constraint_project_hess(mopt_ctx *ctx, int n, const double *H, int c, const double *Q, int cs, const double *S, double k_hard,
+                                            double k_soft, double *H_out) {
+    using namespace mopt;
+    if (!ctx) return MOPT_E_ARG;
+    if (n < 1 || n > MOPT_MAX_N || c < 1 || c > 64 || cs < 0 || cs > 256 || !H || !Q || (cs > 0 && !S) || !H_out) { ctx->err = "mopt_constraint_project_hess: bad arguments"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    const size_t nn = (size_t)n * n * 8;
+    DB dH, dO, dQ, dS, dW1, dW2, dM;
+    CTRY_(dH.alloc(ctx, nn)); CTRY_(dO.alloc(ctx, nn)); CTRY_(dQ.alloc(ctx, (size_t)c * n * 8)); CTRY_(dS.alloc(ctx, (size_t)(cs > 0 ? cs : 1) * n * 8));
+    CTRY_(dW1.alloc(ctx, (size_t)n * c * 8)); CTRY_(dW2.alloc(ctx, (size_t)n * c * 8)); CTRY_(dM.alloc(ctx, (size_t)c * c * 8));
+    CH2D(ctx, dH.p, H, nn); CH2D(ctx, dQ.p, Q, (size_t)c * n * 8);
+    if (cs > 0) CH2D(ctx, dS.p, S, (size_t)cs * n * 8);
+    {
+        mopt_scope sc(ctx, "constraint", 4);
+        hipLaunchKernelGGL(k_cp_w1, dim3(n), dim3(256), 0, ctx->stream, n, c, dH.as<double>(), dQ.as<double>(), dW1.as<double>());
+        hipLaunchKernelGGL(k_cp_w2, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, c, dH.as<double>(), dQ.as<double>(), dW2.as<double>());
+        hipLaunchKernelGGL(k_cp_m, dim3(1), dim3(256), 0, ctx->stream, n, c, dQ.as<double>(), dW1.as<double>(), dM.as<double>());
+        hipLaunchKernelGGL(k_cp_apply, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, n, c, cs, dH.as<double>(), dQ.as<double>(), dS.as<double>(),
+                           dW1.as<double>(), dW2.as<double>(), dM.as<double>(), k_hard, k_soft, dO.as<double>());
+    }
+    CD2H(ctx, H_out, dO.p, nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+// U: n x m (row-major, orthonormal columns: the null space of the constraints).  Everything else as mopt_rsirfo_run with batch 1;
+// B_g is the full-space gradient (after the caller's gradient transport, if any).
+extern "C" int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
+                                const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                                const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym) {
+    using namespace mopt;
+    if (!ctx) return MOPT_E_ARG;
+    if (n < 1 || n > MOPT_MAX_N || m < 1 || m > n || !params || !state || !geom || !B_g || !B_e || !U || !step) { ctx->err = "mopt_crsirfo_run: bad arguments"; return MOPT_E_ARG; }
+    if (!hessian) { ctx->err = "Hessian matrix must be set before running optimization"; return MOPT_E_STATE; }
+    hipSetDevice(ctx->device);
+    RsirfoWork wk, ws;
+    CTRY_(wk.alloc(ctx, n, 1, true, bias_hessian != nullptr, H_inplace != nullptr));
+    CTRY_(ws.alloc(ctx, m, 1, false, false, false));
+    const size_t nn = (size_t)n * n * 8, nv = (size_t)n * 8;
+    CH2D(ctx, wk.H, hessian, nn);
+    if (bias_hessian) CH2D(ctx, wk.Bias, bias_hessian, nn);
+    CH2D(ctx, wk.x, geom, nv); CH2D(ctx, wk.bg, B_g, nv); CH2D(ctx, wk.g, g ? g : B_g, nv);
+    const bool have_prev = pre_geom && pre_g;
+    if (have_prev) { CH2D(ctx, wk.px, pre_geom, nv); CH2D(ctx, wk.pg, pre_g, nv); }
+    const int rule = params->rule;
+    if (rule < 0 || rule >= MOPT_RULE_COUNT) { ctx->err = "unknown update rule"; return MOPT_E_ARG; }
+    const int upd = (have_prev && state->has_prev) ? 1 : 0;
+    CH2D(ctx, wk.rules, &rule, sizeof(int)); CH2D(ctx, wk.do_update, &upd, sizeof(int));
+    CH2D(ctx, ws.params, params, sizeof(mopt_rsirfo_params)); CH2D(ctx, ws.states, state, sizeof(mopt_rsirfo_state));
+    CH2D(ctx, ws.be, B_e, 8);
+    // padded basis: Upad (n x n, U in its first m columns) and its transpose
+    std::vector<double> up((size_t)n * n, 0.0), upt((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) for (int k = 0; k < m; ++k) { const double v = U[(size_t)i * m + k]; up[(size_t)i * n + k] = v; upt[(size_t)k * n + i] = v; }
+    DB dU, dUt, dvec;
+    CTRY_(dU.alloc(ctx, nn)); CTRY_(dUt.alloc(ctx, nn)); CTRY_(dvec.alloc(ctx, 2 * nv));
+    CH2D(ctx, dU.p, up.data(), nn); CH2D(ctx, dUt.p, upt.data(), nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // (the staging vectors go out of use below)
+    const UpdateCoef *coef = nullptr;
+    if (upd) {
+        CTRY_(mopt_launch_hess_update(ctx, n, 1, wk.rules, wk.do_update, rule == MOPT_RULE_FLOWCHART, wk.x, wk.px, wk.g, wk.pg, wk.s, wk.y, wk.u, wk.Hy,
+                                      wk.yd, wk.Av, wk.coef, wk.info, wk.H, wk.Hinpl, wk.H, false));
+        coef = wk.coef;
+    }
+    CTRY_(mopt_launch_sym_add(ctx, n, 1, wk.H, wk.Bias, wk.A));                              // A = sym(H + bias)
+    CTRY_(mopt_launch_dgemm(ctx, n, 1, wk.A, dU.as<double>(), nullptr, wk.Gt));             // A U
+    CTRY_(mopt_launch_dgemm(ctx, n, 1, dUt.as<double>(), wk.Gt, nullptr, wk.Vt));           // U^T A U (leading m x m block)
+    hipLaunchKernelGGL(k_lead_block_sym, dim3((m + 255) / 256, m), dim3(256), 0, ctx->stream, n, m, wk.Vt, ws.A);
+    double *tmp = dvec.as<double>(), *spad = tmp + n;
+    CTRY_(mopt_launch_matvec(ctx, n, 1, dUt.as<double>(), wk.bg, tmp));                     // U^T g (first m entries)
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(ws.gp, tmp, (size_t)m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(ws.bg, tmp, (size_t)m * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    CTRY_(mopt_eigh_auto(ctx, ws, m, 1, false, /*preserve_A=*/false));
+    CTRY_(mopt_launch_rfo(ctx, m, 1, ws.params, ws.states, ws.eigw, ws.perm, ws.einfo, ws.Vt, ws.gp, ws.bg, ws.be, coef, ws.gt_all, ws.coefout, ws.step));
+    hipLaunchKernelGGL(k_pad_copy, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, m, n, ws.step, spad);
+    CTRY_(mopt_launch_matvec(ctx, n, 1, dU.as<double>(), spad, wk.step));                   // step = U step_sub
+    CD2H(ctx, step, wk.step, nv);
+    CD2H(ctx, state, ws.states, sizeof(mopt_rsirfo_state));
+    if (H_sym) CD2H(ctx, H_sym, wk.H, nn);
+    if (H_inplace) CD2H(ctx, H_inplace, upd ? wk.Hinpl : wk.H, nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    if (state->jacobi_sweeps < 0) { ctx->err = "mopt_crsirfo_run: the eigen-solver failed"; return MOPT_E_NUMERIC; }
+    return MOPT_OK;
+}

@@ -182,6 +182,34 @@ extern "C" int mopt_hess_update(mopt_ctx *ctx, int rule, int n, int batch, const
     return MOPT_OK;
 }
 
+namespace { __global__ void __launch_bounds__(256) k_delta(size_t total, const double *__restrict__ Hn, const double *__restrict__ H, double *__restrict__ dH) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) dH[i] = Hn[i] - H[i];
+} }
+
+// delta-H of one update rule WITHOUT RSIRFO.update_hessian's guards: what ModelHessianUpdate.<rule>_hessian_update returns
+// (hessian_update.py:163-433) -- the form the IRC integrators call (IRC/lqa.py:286, IRC/hpc.py:421).
+extern "C" int mopt_hess_delta(mopt_ctx *ctx, int rule, int n, int batch, const double *H, const double *s, const double *y, double *dH) {
+    if (bad_dims(ctx, n, batch) || !H || !s || !y || !dH || rule < 0 || rule >= MOPT_RULE_COUNT) return MOPT_E_ARG;
+    hipSetDevice(ctx->device);
+    const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
+    DBuf dHb, dHi, dHs, ds, dy, du, dHy, dyd, dA, dcoef, dinfo, drules;
+    TRY(dHb.alloc(ctx, nn)); TRY(dHs.alloc(ctx, nn)); TRY(dHi.alloc(ctx, nn));
+    TRY(ds.alloc(ctx, nv)); TRY(dy.alloc(ctx, nv)); TRY(du.alloc(ctx, nv)); TRY(dHy.alloc(ctx, nv)); TRY(dyd.alloc(ctx, nv)); TRY(dA.alloc(ctx, nv));
+    TRY(dcoef.alloc(ctx, batch * sizeof(UpdateCoef))); TRY(dinfo.alloc(ctx, (size_t)batch * 8 * sizeof(double)));
+    TRY(drules.alloc(ctx, batch * sizeof(int)));
+    std::vector<int> rules(batch, rule);
+    H2D(ctx, dHb.p, H, nn); H2D(ctx, ds.p, s, nv); H2D(ctx, dy.p, y, nv); H2D(ctx, drules.p, rules.data(), batch * sizeof(int));
+    TRY(mopt_launch_hess_update(ctx, n, batch, drules.as<int>(), nullptr, rule == MOPT_RULE_FLOWCHART, nullptr, nullptr, nullptr, nullptr,
+                                ds.as<double>(), dy.as<double>(), du.as<double>(), dHy.as<double>(), dyd.as<double>(), dA.as<double>(),
+                                dcoef.as<UpdateCoef>(), dinfo.as<double>(), dHb.as<double>(), dHi.as<double>(), dHs.as<double>(), true, /*guard_sy=*/false));
+    const size_t total = (size_t)batch * n * n;
+    hipLaunchKernelGGL(k_delta, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, total, dHi.as<double>(), dHb.as<double>(), dHs.as<double>());
+    D2H(ctx, dH, dHs.p, nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
 extern "C" int mopt_project_trrot_hess(mopt_ctx *ctx, int n, int batch, const double *H, const double *X, double *Hp) {
     if (bad_dims(ctx, n, batch) || !H || !X || !Hp) return MOPT_E_ARG;
     hipSetDevice(ctx->device);

@@ -375,6 +375,84 @@ def g11_afir():
     print("G11:", len(cases_), "cases")
 
 
+def g12_constraints():
+    """G12: ProjectOutConstrain (Constraint/constraint_condition.py:340-754) -- initial values, SHAKE-like adjustment, gradient
+    projection, three consecutive Hessian projections (history of constraint bases) -- and three consecutive CRSIRFO.run calls
+    (Optimizer/crsirfo.py:15-182) on a quadratic model surface, with bond / angle / dihedral / x constraints on the aldol geometry."""
+    from multioptpy.Constraint.constraint_condition import ProjectOutConstrain
+    from multioptpy.Optimizer.crsirfo import CRSIRFO
+    from multioptpy.ModelHessian.fischerd3old import FischerD3ApproxHessianOld
+    elems, xyz = _read_xyz("/root/reference/test/aldol_rxn.xyz")
+    x0 = xyz / cases.BOHR2ANG
+    N = len(elems)
+    with quiet():
+        K = FischerD3ApproxHessianOld().main(x0.copy(), list(elems), np.zeros_like(x0))
+    rng = np.random.default_rng(12)
+    out = {"x0": x0, "elems": np.array(elems), "K": K}
+    names = ["bond", "angle", "dihedral", "x"]
+    atoms = [[1, 3], [2, 1, 3], [4, 1, 3, 5], [7]]
+    out["names"] = np.array(names)
+    out["atoms_flat"] = np.array([a for lst in atoms for a in lst])
+    out["atoms_len"] = np.array([len(lst) for lst in atoms])
+    # ---- projections
+    with quiet():
+        pc = ProjectOutConstrain(list(names), [list(a) for a in atoms])
+        init = pc.initialize(x0.copy())
+        out["init"] = np.array(init, dtype=float)
+        xs = [x0 + rng.normal(0, 0.03, x0.shape) for _ in range(3)]
+        for k, x in enumerate(xs):
+            g = rng.normal(size=(N, 3))
+            H = K + 0.05 * np.eye(3 * N) * k
+            out[f"p{k}_x"], out[f"p{k}_g"], out[f"p{k}_Hin"] = x, g, H
+            out[f"p{k}_B"] = np.array(pc._get_all_constraint_vectors(x))
+            out[f"p{k}_gproj"] = np.array(pc.calc_project_out_grad(x.copy(), g.copy()))
+            out[f"p{k}_Hproj"] = np.array(pc.calc_project_out_hess(x.copy(), g.copy(), H.copy()))
+        xa = x0 + rng.normal(0, 0.05, x0.shape)
+        out["shake_in"] = xa
+        out["shake_out"] = np.array(pc.adjust_init_coord(xa.copy()))
+        out["shake_iters"] = np.array(pc.last_shake_iter)
+    # ---- CRSIRFO on E = 1/2 (x - x0) K (x - x0) + d.(x - x0)
+    d = 0.01 * rng.normal(size=x0.size)
+    # a physical linear term: no net force or torque (the model surface's curvature K has exact TR/rot zero modes at x0, and CRSIRFO
+    # does not project them out -- a gradient with components along them would make the step ill-conditioned for any solver)
+    Tr = np.zeros((6, x0.size))
+    xc = x0 - x0.mean(axis=0)
+    for a in range(len(x0)):
+        for c in range(3):
+            Tr[c, 3 * a + c] = 1.0
+        Tr[3, 3 * a:3 * a + 3] = [0.0, -xc[a, 2], xc[a, 1]]
+        Tr[4, 3 * a:3 * a + 3] = [xc[a, 2], 0.0, -xc[a, 0]]
+        Tr[5, 3 * a:3 * a + 3] = [-xc[a, 1], xc[a, 0], 0.0]
+    Qtr, _ = np.linalg.qr(Tr.T)
+    d = d - Qtr @ (Qtr.T @ d)
+    out["d"] = d
+    with quiet():
+        pc2 = ProjectOutConstrain(list(names[:2]), [list(a) for a in atoms[:2]])
+        pc2.initialize(x0.copy())
+        opt = CRSIRFO(constraints=pc2, method="rsirfo_fsb", saddle_order=0)
+        x = x0 + rng.normal(0, 0.02, x0.shape)
+        px = pg = None
+        pE = 0.0
+        for it in range(3):
+            dx = (x - x0).reshape(-1)
+            E = 0.5 * dx @ K @ dx + d @ dx
+            g = (K @ dx + d).reshape(-1, 1)
+            opt.set_bias_hessian(np.zeros_like(K))
+            if it == 0:
+                opt.set_hessian(K.copy())
+                s = opt.run(x.reshape(-1, 1).copy(), g.copy(), [], [], E, 0.0, [], [], g.copy(), [])
+            else:
+                s = opt.run(x.reshape(-1, 1).copy(), g.copy(), pg, px, E, pE, [], [], g.copy(), pg)
+            out[f"c{it}_x"], out[f"c{it}_g"], out[f"c{it}_E"] = x.copy(), g.copy(), np.array(E)
+            out[f"c{it}_step"] = np.asarray(s).copy()
+            out[f"c{it}_tr"] = np.array(opt.trust_radius)
+            out[f"c{it}_H"] = np.array(opt.hessian).copy()
+            px, pg, pE = x.reshape(-1, 1).copy(), g.copy(), E
+            x = (x.reshape(-1, 1) - s).reshape(-1, 3)
+    np.savez_compressed(os.path.join(HERE, "g12_constraints.npz"), **out)
+    print("G12 written")
+
+
 BRENT_FUNCS = {
     "cubic": (lambda t: t ** 3 - 2 * t - 5, 2.0, 3.0),
     "cosx": (lambda t: np.cos(t) - t, 0.0, 1.0),
@@ -731,7 +809,7 @@ def g8_nebmain():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g11", "g12"]
     if "g1" in which:
         g1_updates()
     if "g2" in which:
@@ -742,6 +820,8 @@ if __name__ == "__main__":
         g10_model_hessian()
     if "g11" in which:
         g11_afir()
+    if "g12" in which:
+        g12_constraints()
     if "g4" in which:
         g4_brentq()
     if "g5" in which:

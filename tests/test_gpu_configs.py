@@ -463,3 +463,81 @@ def test_rsirfo_with_afir_bias_vs_oracle():
     for a, b in zip(outs[0][0], outs[1][0]):
         assert np.abs(a - b).max() < 1e-8, np.abs(a - b).max()
     assert np.abs(outs[0][1] - outs[1][1]).max() < 1e-8 and abs(outs[0][2] - outs[1][2]) < 1e-12
+
+
+# ---- constraints and the constrained RS-I-RFO -------------------------------------------------------------
+def _g12():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g12_constraints.npz"))
+    names = [str(s) for s in z["names"]]
+    atoms, k = [], 0
+    for ln in z["atoms_len"]:
+        atoms.append([int(a) for a in z["atoms_flat"][k:k + int(ln)]])
+        k += int(ln)
+    return z, names, atoms
+
+
+def test_constraint_hessian_projection_vs_reference():
+    """G12: three consecutive ProjectOutConstrain.calc_project_out_hess calls (hard wall + history-based soft wall, smoothed stiffness)
+    with the O(n^2) part on the device, against the reference's outputs."""
+    from multioptpy_amd.Constraint.constraint_condition import ProjectOutConstrain
+    z, names, atoms = _g12()
+    pc = ProjectOutConstrain(names, atoms)
+    pc.initialize(z["x0"])
+    for k in range(3):
+        out = pc.calc_project_out_hess(z[f"p{k}_x"], z[f"p{k}_g"], z[f"p{k}_Hin"])
+        err = np.abs(out - z[f"p{k}_Hproj"]).max()
+        assert err < 1e-8 * max(1.0, np.abs(z[f"p{k}_Hproj"]).max()), (k, err)
+
+
+def test_crsirfo_traces_vs_reference():
+    """G12: three consecutive CRSIRFO.run calls (bond + angle constraints, SHAKE-like correction, subspace RFO) against the reference:
+    step (<= 1e-8), trust radius, updated Hessian."""
+    from multioptpy_amd.Constraint.constraint_condition import ProjectOutConstrain
+    from multioptpy_amd.Optimizer.crsirfo import CRSIRFO
+    z, names, atoms = _g12()
+    pc = ProjectOutConstrain(names[:2], atoms[:2])
+    pc.initialize(z["x0"])
+    opt = CRSIRFO(constraints=pc, method="rsirfo_fsb", saddle_order=0)
+    K = z["K"]
+    px = pg = None
+    pE = 0.0
+    for it in range(3):
+        x, g, E = z[f"c{it}_x"], z[f"c{it}_g"], float(z[f"c{it}_E"])
+        opt.set_bias_hessian(np.zeros_like(K))
+        if it == 0:
+            opt.set_hessian(K.copy())
+            s = opt.run(x.reshape(-1, 1).copy(), g.copy(), [], [], E, 0.0, [], [], g.copy(), [])
+        else:
+            s = opt.run(x.reshape(-1, 1).copy(), g.copy(), pg, px, E, pE, [], [], g.copy(), pg)
+        assert np.abs(s - z[f"c{it}_step"]).max() < 1e-8, (it, np.abs(s - z[f"c{it}_step"]).max())
+        assert abs(opt.trust_radius - float(z[f"c{it}_tr"])) < 1e-12
+        assert np.abs(np.asarray(opt.hessian) - z[f"c{it}_H"]).max() < 1e-8
+        px, pg, pE = x.reshape(-1, 1).copy(), g.copy(), E
+
+
+def test_model_hessian_update_class_for_irc_reuse():
+    """ModelHessianUpdate.<rule>_hessian_update(hess, dx, dg) -> delta-H, the form the IRC integrators call (IRC/lqa.py:286 FSB,
+    IRC/hpc.py:421 BFGS), against the reference's delta-H of G1 -- including the cases RSIRFO.update_hessian's own guards would skip."""
+    import os
+    from multioptpy_amd.Optimizer.hessian_update import ModelHessianUpdate
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g1_updates.npz"))
+    mhu = ModelHessianUpdate()
+    name_of = {"rsirfo_bfgs": "BFGS_hessian_update", "rsirfo_fsb": "FSB_hessian_update", "rsirfo_sr1": "SR1_hessian_update",
+               "rsirfo_psb": "PSB_hessian_update", "rsirfo_bofill": "Bofill_hessian_update", "rsirfo_msp": "MSP_hessian_update",
+               "rsirfo_cfd_fsb": "CFD_FSB_hessian_update", "rsirfo_bfgs_dd": "BFGS_hessian_update_dd"}
+    ncase = sum(1 for k in z.files if k.endswith("_delta"))
+    checked = 0
+    for i in range(ncase):
+        tag = f"c{i:03d}"
+        method = str(z[tag + "_method"])
+        if method not in name_of:
+            continue
+        n, indef, seed = z[tag + "_meta"]
+        H = cases.spd_matrix(int(n), seed=int(n) + int(indef), indefinite=bool(indef))
+        s, y = cases.sy_pair(H, seed=int(seed), kind=str(z[tag + "_kind"]))
+        dH = getattr(mhu, name_of[method])(H, s.reshape(-1, 1), y.reshape(-1, 1))
+        ref = z[tag + "_delta"]
+        assert np.abs(dH - ref).max() / max(1.0, np.abs(ref).max()) < 1e-9, (tag, method)
+        checked += 1
+    assert checked >= 100

@@ -353,3 +353,66 @@ def test_g11_afir_oracle_vs_reference():
         cov = mh.element_params(el)["cov"]
         E, g, H = afir.afir(z[t + "_x"], cov, list(z[t + "_f1"]), list(z[t + "_f2"]), float(z[t + "_gamma"]))
         assert abs(E - float(z[t + "_E"])) < 1e-14 and np.abs(g - z[t + "_g"]).max() < 1e-14 and np.abs(H - z[t + "_H"]).max() < 1e-14, t
+
+
+def _g12():
+    z = np.load(os.path.join(G, "g12_constraints.npz"))
+    names = [str(s) for s in z["names"]]
+    atoms, k = [], 0
+    for ln in z["atoms_len"]:
+        atoms.append([int(a) for a in z["atoms_flat"][k:k + int(ln)]])
+        k += int(ln)
+    return z, names, atoms
+
+
+def test_g12_constraints_oracle_vs_reference():
+    """G12: ProjectOutConstrain (initial values, SHAKE-like adjustment, constraint rows up to sign, gradient projection, three Hessian
+    projections with history) and three CRSIRFO.run calls of the reference against the oracle."""
+    import contextlib
+    import io
+    from oracle import constraint as oc
+    z, names, atoms = _g12()
+    pc = oc.ProjectOutConstrain(names, atoms)
+    assert np.abs(np.array(pc.initialize(z["x0"])) - z["init"]).max() < 1e-14
+    for k in range(3):
+        x, g, H = z[f"p{k}_x"], z[f"p{k}_g"], z[f"p{k}_Hin"]
+        B = pc.constraint_vectors(x)
+        for i in range(len(B)):
+            assert min(np.abs(B[i] - z[f"p{k}_B"][i]).max(), np.abs(B[i] + z[f"p{k}_B"][i]).max()) < 1e-12
+        assert np.abs(pc.calc_project_out_grad(x, g) - z[f"p{k}_gproj"]).max() < 1e-13
+        assert np.abs(pc.calc_project_out_hess(x, g, H) - z[f"p{k}_Hproj"]).max() < 1e-11
+    assert np.abs(pc.adjust_init_coord(z["shake_in"].copy()) - z["shake_out"]).max() < 1e-13
+    pc2 = oc.ProjectOutConstrain(names[:2], atoms[:2])
+    pc2.initialize(z["x0"])
+    opt = oc.CRSIRFO(constraints=pc2, method="rsirfo_fsb", saddle_order=0)
+    K = z["K"]
+    px = pg = None
+    pE = 0.0
+    for it in range(3):
+        x, g, E = z[f"c{it}_x"], z[f"c{it}_g"], float(z[f"c{it}_E"])
+        opt.set_bias_hessian(np.zeros_like(K))
+        with contextlib.redirect_stdout(io.StringIO()):
+            if it == 0:
+                opt.set_hessian(K.copy())
+                s = opt.run(x.reshape(-1, 1).copy(), g.copy(), [], [], E, 0.0, [], [], g.copy(), [])
+            else:
+                s = opt.run(x.reshape(-1, 1).copy(), g.copy(), pg, px, E, pE, [], [], g.copy(), pg)
+        assert np.abs(s - z[f"c{it}_step"]).max() < 1e-9, it
+        assert abs(opt.trust_radius - float(z[f"c{it}_tr"])) < 1e-12 and np.abs(opt.hessian - z[f"c{it}_H"]).max() < 1e-12
+        px, pg, pE = x.reshape(-1, 1).copy(), g.copy(), E
+
+
+def test_g12_constraint_host_parts_of_the_plugin_class():
+    """The host side of multioptpy_amd's ProjectOutConstrain (no GPU: rows, basis, gradient projection, SHAKE-like adjustment)."""
+    from multioptpy_amd.Constraint.constraint_condition import ProjectOutConstrain
+    z, names, atoms = _g12()
+    pc = ProjectOutConstrain(names, atoms)
+    assert np.abs(np.array(pc.initialize(z["x0"])) - z["init"]).max() < 1e-14
+    for k in range(3):
+        B = pc._get_all_constraint_vectors(z[f"p{k}_x"])
+        for i in range(len(B)):
+            assert min(np.abs(B[i] - z[f"p{k}_B"][i]).max(), np.abs(B[i] + z[f"p{k}_B"][i]).max()) < 1e-12
+        assert np.abs(pc.calc_project_out_grad(z[f"p{k}_x"], z[f"p{k}_g"]) - z[f"p{k}_gproj"]).max() < 1e-13
+    assert np.abs(pc.adjust_init_coord(z["shake_in"].copy()) - z["shake_out"]).max() < 1e-13
+    with pytest.raises(NotImplementedError):
+        ProjectOutConstrain(["rot"], [[1, 2, 3]])
