@@ -252,6 +252,8 @@ __global__ void __launch_bounds__(256) k_dc_prep(int n, int L, int lev, DcPtrs p
     __syncthreads();
     zmx = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
     dmx = fmax(fmax(s_red[4], s_red[5]), fmax(s_red[6], s_red[7]));
+    for (int i = tid; i < m; i += blockDim.x) order[i] = i;      // (a valid permutation even if NaNs make ranks collide)
+    __syncthreads();
     for (int i = tid; i < m; i += blockDim.x) {            // rank sort (ties by index)
         const double di = d[i];
         int r = 0;

@@ -275,7 +275,6 @@ __global__ void __launch_bounds__(1024) k_backtransform(int n, const double *__r
 
 }  // namespace mopt
 
-static int g_rfo_lds_attr_done = 0;
 
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,
@@ -284,10 +283,7 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
     using namespace mopt;
     mopt_scope sc(ctx, "rfo", 3);
     const size_t lds = (size_t)9 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
-    if (!g_rfo_lds_attr_done) {
-        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-        g_rfo_lds_attr_done = 1;
-    }
+    if (lds > 48000) MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
     hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_gp, d_einfo, d_gt_all);
     hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(64), lds, ctx->stream, n, d_params, d_states, d_W, d_perm, d_einfo,
                        d_gt_all, d_Bg, d_Be, d_coef, d_coefout, getenv("MOPT_RFO_DBG") ? 1 : 0);

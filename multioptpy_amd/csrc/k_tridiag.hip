@@ -1367,7 +1367,10 @@ __global__ void __launch_bounds__(256) k_dc_flag(int n, const double *__restrict
         }
     }
     big = __syncthreads_or(big);
-    if (tid == 0) dcflag_[b] = big;
+    int nonfin = 0;
+    for (int i = tid; i < n; i += blockDim.x) nonfin |= (!isfinite(D[i]) || (i < n - 1 && !isfinite(E[i]))) ? 1 : 0;
+    nonfin = __syncthreads_or(nonfin);
+    if (tid == 0) dcflag_[b] = (big && !nonfin) ? 1 : 0;      // (k_tri_bisect handles non-finite matrices)
 }
 
 // Eigenvalues by multi-section.  Workgroup (p, b) handles eigenvalues [64 p, 64 p + 64) of matrix b with 512 threads: the
@@ -1389,8 +1392,18 @@ __global__ void __launch_bounds__(BIS_THREADS) k_tri_bisect(int n, const double 
     const double *D = D_ + (size_t)b * n;
     double *E = E_ + (size_t)b * n, *WT = WT_ + (size_t)b * n, *onenrm = onenrm_ + (size_t)b * n;
     int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n;
-    for (int i = tid; i < n; i += blockDim.x) { d[i] = D[i]; e[i] = (i < n - 1) ? E[i] : 0.0; }
-    __syncthreads();
+    int nonfin = 0;
+    for (int i = tid; i < n; i += blockDim.x) { d[i] = D[i]; e[i] = (i < n - 1) ? E[i] : 0.0; nonfin |= (!isfinite(d[i]) || !isfinite(e[i])) ? 1 : 0; }
+    nonfin = __syncthreads_or(nonfin);
+    if (nonfin) {
+        // a non-finite matrix (NaN / Inf Hessian): no solve -- every index becomes a block of its own with a NaN eigenvalue, which
+        // k_tri_sort reports as "non-finite" (identity fallback in the RFO kernels); nothing downstream iterates on NaNs
+        if (blockIdx.x == 0) {
+            for (int i = tid; i < n; i += blockDim.x) { bstart[i] = i; bend[i] = i + 1; WT[i] = NAN; onenrm[i] = 1.0; }
+            if (dcflag_ && tid == 0) dcflag_[b] = 0;
+        }
+        return;
+    }
     // splitting.  dstebz drops e_i when e_i^2 <= ulp^2 |d_i d_{i+1}|; the Hessians of this path are often identity + low rank
     // (rfo_neb.py:25), whose reduced form carries off-diagonals of a few sqrt(n) ulp between hundreds of numerically equal
     // diagonal entries -- left in place they form one giant cluster for the inverse iteration.  Dropping |e_i| <= 32 ulp
@@ -1977,12 +1990,13 @@ __global__ void __launch_bounds__(1024) k_tri_sort(int n, int npow2, const doubl
     }
     // info word: 1 non-finite eigenvalues, 4 the solver failed for this matrix, 8 (with 4) the failure was a hand-off time-out of the
     // persistent tridiagonalisation (GPU shared with a long-running kernel), not a numerical one
-    if (threadIdx.x == 0) { const int f = fail_[b]; info[2 * b] = 0; info[2 * b + 1] = bad | (f ? 4 : 0) | (f >= TRI_FAIL_TIMEOUT ? 8 : 0); }
+    // Non-finite eigenvalues (a NaN / Inf Hessian, rsirfo.py:365-372: "common for linear molecules and poor initial guesses") are not
+    // a solver failure: the consumers replace such an eigen-system by (w = 1, V = I) and continue as steepest descent, as the reference.
+    if (threadIdx.x == 0) { const int f = fail_[b]; info[2 * b] = 0; info[2 * b + 1] = bad ? 1 : ((f ? 4 : 0) | (f >= TRI_FAIL_TIMEOUT ? 8 : 0)); }
 }
 
 }  // namespace mopt
 
-static int g_tri_attr = 0, g_tri_attr2 = 0;
 // Developer switches are read from the environment once per process and name (a launch used to call getenv a dozen times).
 #include <map>
 #include <mutex>
@@ -2011,11 +2025,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                              double *d_W, int *d_perm, int *d_info, double *d_Z2) {
     using namespace mopt;
     if (n < 3) { ctx->err = "tridiagonal eigen-solver needs n >= 3"; return MOPT_E_ARG; }
-    if (!g_tri_attr) {
-        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_invit, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-        g_tri_attr = 1;
-    }
+    // (set on every call: contexts of several devices live in one process, and the attribute is per device)
+    MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_invit, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+    MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
     const bool multi = !(tri_env("MOPT_TRI_SINGLE")) && n >= 32;
     const bool no_persist = ctx->tri_no_persist || tri_env("MOPT_TRI_NOPERSIST");
     MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
@@ -2216,10 +2228,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
     } else if (persist) {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
-        if (!g_tri_attr2) {
-            MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_persist, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-            g_tri_attr2 = 1;
-        }
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_persist, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
         const int rows = rows_for(G);
         long long *d_prof = nullptr;
         if (tri_env("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
@@ -2309,11 +2318,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork4, 0));
             // (two instantiations: one wave for blocks of 2 .. 32 rows, two waves for 33 .. 64 rows -- the Hessians of a long NEB
             // run grow blocks of 33-48 rows around a ~20-fold eigenvalue, which cost the inverse iteration 2-3 ms per cluster)
-            static int small_attr = 0;
-            if (!small_attr) {
-                MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_small<64, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-                small_attr = 1;
-            }
+            MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_small<64, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
             if (small_max > 0)
                 hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
             if (small_max > 32)

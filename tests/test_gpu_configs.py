@@ -541,3 +541,75 @@ def test_model_hessian_update_class_for_irc_reuse():
         assert np.abs(dH - ref).max() / max(1.0, np.abs(ref).max()) < 1e-9, (tag, method)
         checked += 1
     assert checked >= 100
+
+
+def test_ayala_gamma_direct_vs_reference():
+    """a17: calculate_gamma (pathopt_bneb_force.py:161-222) asserted directly.  At band step 0 no quasi-Newton update is applied, so an
+    image's resident Hessian after the step is  I + gamma t t^T  (rfo_neb.py:72) with t = tangent_grad: gamma of the kernel = the
+    reference's value from G6 for every interior image of every fixture."""
+    import os
+    from multioptpy_amd.band import Band
+    from multioptpy_amd import ops
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g6_neb_force.npz"))
+    tags = sorted({k.split("_")[0] for k in z.files if k.endswith("_gamma")})
+    checked = 0
+    for tag in tags:
+        if int(z[tag + "_ci"]) != 0:
+            continue                                   # (gamma does not depend on the CI switch; one copy of each geometry is enough)
+        X, E, G = z[tag + "_X"], z[tag + "_E"], z[tag + "_G"]
+        I, N = X.shape[0], X.shape[1]
+        n = 3 * N
+        _, tau = ops.bneb_force(X, E, G)
+        band = Band(I, N)
+        band.upload(X, E, G)
+        band.step(0)
+        band.download()
+        for i in range(1, I - 1):
+            t = tau[i].reshape(-1)
+            H = band.get_hessian(i)
+            gam = float(z[tag + "_gamma"][i])
+            assert np.abs(H - (np.eye(n) + gam * np.outer(t, t))).max() < 1e-10 * max(1.0, abs(gam) * (t @ t)), (tag, i)
+            tt = t @ t
+            if tt > 1e-12:
+                assert abs(t @ (H - np.eye(n)) @ t / tt ** 2 - gam) < 1e-8 * max(1.0, abs(gam)), (tag, i)
+            checked += 1
+        band.close()
+    assert checked >= 12
+
+
+@pytest.mark.parametrize("N", [7, 22, 100])
+def test_rsirfo_nan_hessian_identity_fallback(N):
+    """A NaN-poisoned Hessian.  The reference's RSIRFO.run replaces a non-finite eigen-system by (w = 1, V = I) and carries on as
+    steepest descent (rsirfo.py:365-372, 432-436) -- with numpy 2.2 its own `np.linalg.eigh` raises LinAlgError on NaN input before that
+    branch is reached, so the branch is only live where eigh returns NaNs.  The device path implements the documented intent: a finite
+    step equal to the oracle's when the oracle's eigh hands back NaNs instead of raising; on both eigen-solver routes."""
+    import warnings
+    from multioptpy_amd.Optimizer.rsirfo import RSIRFO
+    import oracle.rsirfo as orf
+    x = cases.cluster(N)
+    E, G, H = cases.lj(x, hessian=True)
+    H = H.copy()
+    H[3, 5] = H[5, 3] = np.nan
+    g = G.reshape(-1, 1).copy()
+    opt = RSIRFO(method="rsirfo_bfgs", saddle_order=0)
+    opt.set_hessian(H.copy())
+    opt.set_bias_hessian(np.zeros_like(H))
+    dev = np.asarray(opt.run(x.reshape(-1, 1).copy(), g.copy(), [], [], E, 0.0, [], [], g.copy(), []))
+    assert np.all(np.isfinite(dev)), "the device step must be finite"
+    real_eigh = np.linalg.eigh
+
+    def eigh_nan(A):
+        if not np.all(np.isfinite(A)):
+            return np.full(A.shape[0], np.nan), np.full(A.shape, np.nan)
+        return real_eigh(A)
+    ref_opt = orf.RSIRFO(method="rsirfo_bfgs", saddle_order=0)
+    ref_opt.set_hessian(H.copy())
+    ref_opt.set_bias_hessian(np.zeros_like(H))
+    orf.np.linalg.eigh = eigh_nan
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = np.asarray(ref_opt.run(x.reshape(-1, 1).copy(), g.copy(), [], [], E, 0.0, [], [], g.copy(), []))
+    finally:
+        orf.np.linalg.eigh = real_eigh
+    assert np.abs(dev - ref).max() < 1e-8, np.abs(dev - ref).max()
