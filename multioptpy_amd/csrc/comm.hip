@@ -49,9 +49,12 @@ std::mutex g_rccl_mu;
 bool rccl_load() {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.h) return true;
-    const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // An RCCL that is already in the process (PyTorch brings its own, built against the HIP runtime it also brings and that this
+    // library then shares) is taken first: two RCCL copies on two HIP builds in one process is the configuration to avoid.
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
-    for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (h) break; }
+    if (!h) for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
     if (!h) { g_rccl.err = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return false; }
 #define SYM(field, name) do { g_rccl.field = (decltype(g_rccl.field))dlsym(h, name); if (!g_rccl.field) { g_rccl.err = std::string("librccl.so lacks ") + name; dlclose(h); return false; } } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");

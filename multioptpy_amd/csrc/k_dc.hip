@@ -19,6 +19,7 @@
 
 #include "pipeline.h"
 #include "dc_logic.h"
+#include "ql_block.hpp"
 
 namespace mopt {
 
@@ -126,7 +127,6 @@ __global__ void __launch_bounds__(256) k_dc_setup(int n, int L, const double *__
 // of 19 rows takes ~2.5 QL steps per eigenvalue, ~500 rotations in all -- the one-sided Jacobi of k_tri_small needed ~200 us
 // for the same leaves (LDS round trips and a barrier per round).
 // grid (2^L, B), block 64.  Writes dv[s .. t) and rows s .. t-1 of X (zero outside the leaf).
-__device__ __forceinline__ double dc_rl(double v, int lane) { return lane_bcast(v, lane); }
 __global__ void __launch_bounds__(64) k_dc_leaf(int n, int L, DcPtrs p, double *__restrict__ dv_, double *__restrict__ X_, int *__restrict__ fail_) {
     __shared__ double Zs[32 * 32];
     const int b = blockIdx.y, lane = threadIdx.x;
@@ -137,67 +137,7 @@ __global__ void __launch_bounds__(64) k_dc_leaf(int n, int L, DcPtrs p, double *
     double e = (lane < m - 1) ? p.E2[o + lane] : 0.0;
     for (int c = 0; c < m; ++c) Zs[c * 32 + (lane & 31)] = ((lane & 31) == c) ? 1.0 : 0.0;      // (lanes 32 .. 63 mirror 0 .. 31: same values)
     __syncthreads();
-    bool failed = false;
-    for (int l = 0; l < m; ++l) {
-        int iter = 0;
-        for (;;) {
-            // smallest mm >= l with a negligible e_mm (mm = m - 1 when there is none)
-            const double dn = __shfl_down(d, 1, WAVE);
-            const bool small = (lane >= l && lane < m - 1) ? (fabs(e) <= DC_EPS * (fabs(d) + fabs(dn))) : (lane == m - 1);
-            const unsigned long long bal = __ballot(small) & ~((1ull << l) - 1ull);
-            const int mm = __ffsll((long long)bal) - 1;
-            if (mm == l) break;
-            if (++iter > 60) { failed = true; break; }
-            const double dl_ = dc_rl(d, l), el = dc_rl(e, l), dl1 = dc_rl(d, l + 1);
-            double g = (dl1 - dl_) / (2.0 * el);
-            double r = sqrt(fma(g, g, 1.0));
-            g = dc_rl(d, mm) - dl_ + el / (g + copysign(r, g));      // (Wilkinson shift: once per QL step, IEEE division and root)
-            double sn = 1.0, cs = 1.0, pp = 0.0;
-            bool broke = false;
-            // eigenvector columns: column i + 1 is carried in a register from one rotation to the next (the rotation of (i, i + 1)
-            // leaves the new column i, which is the upper partner of the next rotation), column i - 1 is requested one rotation
-            // ahead -- no LDS round trip on the chain
-            const int lr = lane & 31;
-            double zc = Zs[mm * 32 + lr];
-            double znext = Zs[(mm - 1) * 32 + lr];
-            for (int i = mm - 1; i >= l; --i) {
-                const double ei = dc_rl(e, i);
-                const double di1 = dc_rl(d, i + 1), di = dc_rl(d, i);
-                const double z0 = znext;
-                if (i > l) znext = Zs[(i - 1) * 32 + lr];
-                double f = sn * ei;
-                const double bq = cs * ei;
-                const double x2 = fma(f, f, g * g);
-                if (!(x2 >= 1e-290)) {                       // (underflow or zero: recover as tql2 does)
-                    if (lane == i + 1) { e = sqrt(x2); d -= pp; }
-                    if (lane == mm) e = 0.0;
-                    if (lane < 32) Zs[(i + 1) * 32 + lr] = zc;
-                    zc = z0;                                 // (column i is untouched; written back behind the loop)
-                    broke = true;
-                    if (lane < 32) Zs[i * 32 + lr] = zc;
-                    break;
-                }
-                // the rotation from one reciprocal square root (a few ulp; the accumulated table stays orthogonal to ~m eps)
-                const double rinv = dc_rsqrt(x2);
-                r = x2 * rinv;
-                if (lane == i + 1) e = r;
-                sn = f * rinv; cs = g * rinv;
-                g = di1 - pp;
-                r = (di - g) * sn + 2.0 * cs * bq;
-                pp = sn * r;
-                if (lane == i + 1) d = g + pp;
-                g = cs * r - bq;
-                if (lane < 32) Zs[(i + 1) * 32 + lr] = sn * z0 + cs * zc;
-                zc = cs * z0 - sn * zc;
-            }
-            if (!broke && lane < 32) Zs[l * 32 + lr] = zc;
-            if (!broke) {
-                if (lane == l) { d -= pp; e = g; }
-                if (lane == mm) e = 0.0;
-            }
-        }
-        if (failed) break;
-    }
+    const bool failed = !ql_block32(m, d, e, Zs, lane);
     __syncthreads();
     if (failed && lane == 0) atomicAdd(&fail_[b], 1);
     if (lane < m) dv_[o + lane] = d;

@@ -24,6 +24,7 @@
 #include <vector>
 #include "pipeline.h"
 #include "dc_logic.h"
+#include "ql_block.hpp"
 
 namespace mopt {
 
@@ -1611,6 +1612,39 @@ __global__ void __launch_bounds__(MAXM * 2) k_tri_small(int n, const double *__r
     }
 }
 
+// The same small blocks (2 .. 32 rows) by implicit QL (ql_block.hpp), one wave per block: ~2.5 m^2 / 2 dependent rotations of ~0.27 us
+// instead of 5-7 Jacobi sweeps of m - 1 LDS-synchronised rounds.  Degenerate eigenvalues (the 6-9-fold clusters of the projected
+// identity part) are no special case for QL: the coupling elements go to zero and the block deflates.  The block is scaled to unit
+// max-norm for the iteration.  Same contract as k_tri_small: WT[s .. t) and rows s .. t-1 of Zt (zero outside the block).
+__global__ void __launch_bounds__(64) k_tri_ql32(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
+                                                 const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_, int *__restrict__ fail_,
+                                                 const int *__restrict__ dcflag_) {
+    __shared__ double Zs[32 * 32];
+    if (dcflag_ && dcflag_[blockIdx.y]) return;
+    const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;
+    const int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n;
+    if (bstart[i0] != i0) return;
+    const int s = i0, t = bend[i0], m = t - s;
+    if (m < 2 || m > 32) return;
+    const double *D = D_ + (size_t)b * n + s, *E = E_ + (size_t)b * n + s;
+    double d = (lane < m) ? D[lane] : 0.0;
+    double e = (lane < m - 1) ? E[lane] : 0.0;
+    const double nrm = wave_max(fmax(fabs(d), fabs(e)));
+    const double sc = (nrm > 0.0) ? nrm : 1.0;
+    d /= sc; e /= sc;
+    for (int c = 0; c < m; ++c) Zs[c * 32 + (lane & 31)] = ((lane & 31) == c) ? 1.0 : 0.0;
+    __syncthreads();
+    const bool ok = ql_block32(m, d, e, Zs, lane);
+    __syncthreads();
+    if (!ok && lane == 0) atomicAdd(&fail_[b], 1);
+    if (lane < m) WT_[(size_t)b * n + s + lane] = d * sc;
+    double *Zt = Zt_ + (size_t)b * n * n;
+    for (int c = 0; c < m; ++c) {
+        double *z = Zt + (size_t)(s + c) * n;
+        for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Zs[c * 32 + (i - s)] : 0.0;
+    }
+}
+
 // Membership of vector j in a loose (1e-3) cluster that spans more than one tight cluster inside a block solved by inverse
 // iteration: such clusters are orthogonalised by the Loewdin passes.  Returns the cluster [j0, j1) and the block [s, t).
 __device__ __forceinline__ bool loose_cluster_of(int n, int batch, int b, int j, const int *bstart_, const int *bend_, const int *cstart_,
@@ -2319,7 +2353,11 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             // (two instantiations: one wave for blocks of 2 .. 32 rows, two waves for 33 .. 64 rows -- the Hessians of a long NEB
             // run grow blocks of 33-48 rows around a ~20-fold eigenvalue, which cost the inverse iteration 2-3 ms per cluster)
             MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_small<64, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-            if (small_max > 0)
+            // blocks of 2 .. 32 rows: implicit QL (MOPT_TRI_QL=0: the one-sided Jacobi of round 1)
+            const bool use_ql = !(tri_env("MOPT_TRI_QL") && atoi(tri_env("MOPT_TRI_QL")) == 0);
+            if (small_max > 0 && use_ql)
+                hipLaunchKernelGGL(k_tri_ql32, dim3(n, batch), dim3(64), 0, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
+            else if (small_max > 0)
                 hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
             if (small_max > 32)
                 hipLaunchKernelGGL((k_tri_small<64, 33>), dim3(n, batch), dim3(128), (size_t)2 * 64 * 65 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);

@@ -298,6 +298,21 @@ MOPT_HD inline void push3(double *arr, int32_t &n, double v) {   // "if len >= 3
 // R is a reducer: R.sum(m, f) = sum_i f(i); R.min_index(m, pred) = first i with pred(i) or m;
 // R.for_each(m, f) runs f(i) for every i (lane-strided on the device).
 // ---------------------------------------------------------------------------------------
+// Quotient inside the secular sums.  On the device: hardware reciprocal estimate + two Newton steps (|den| >= 1e-30 is a normal number;
+// ~1 ulp).  The sums only steer Newton / bisection iterates whose stopping tests are 1e-10-relative, and the step itself is formed
+// with IEEE division (solve_rfo); on the host (logic tests): IEEE division.  One f64 division is ~30 dependent instructions on gfx950,
+// and k_rfo_scalar spent 57 of its 72 us in ~40 secular evaluations of 10 divisions per lane.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ double sec_quot(double a, double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return a * r;
+}
+#else
+inline double sec_quot(double a, double b) { return a / b; }
+#endif
+
 MOPT_HD inline double safe_den(double d, double floor_) {
     if (fabs(d) < floor_) {
         double sg = (d > 0.0) ? 1.0 : ((d < 0.0) ? -1.0 : 0.0);
@@ -313,7 +328,7 @@ MOPT_HD inline double safe_den(double d, double floor_) {
 template <class R>
 MOPT_HD double secular_f(const R &red, double lmd, const double *w, const double *gt, int m, double alpha, const double *cg2 = nullptr,
                          const double *cw = nullptr) {
-    if (cg2) return lmd + red.sum(m, [=](int i) { return cg2[i] / safe_den(cw[i] - lmd, 1e-30); });
+    if (cg2) return lmd + red.sum(m, [=](int i) { return sec_quot(cg2[i], safe_den(cw[i] - lmd, 1e-30)); });
     return lmd + red.sum(m, [=](int i) {
         double gp = gt[i] / alpha;
         return (gp * gp) / safe_den(w[i] / alpha - lmd, 1e-30);
@@ -323,7 +338,7 @@ MOPT_HD double secular_f(const R &red, double lmd, const double *w, const double
 template <class R>
 MOPT_HD double secular_fp(const R &red, double lmd, const double *w, const double *gt, int m, double alpha, const double *cg2 = nullptr,
                           const double *cw = nullptr) {
-    if (cg2) return 1.0 + red.sum(m, [=](int i) { double dd = safe_den(cw[i] - lmd, 1e-30); return cg2[i] / (dd * dd); });
+    if (cg2) return 1.0 + red.sum(m, [=](int i) { double dd = safe_den(cw[i] - lmd, 1e-30); return sec_quot(cg2[i], dd * dd); });
     return 1.0 + red.sum(m, [=](int i) {
         double gp = gt[i] / alpha;
         double dd = safe_den(w[i] / alpha - lmd, 1e-30);
@@ -364,7 +379,7 @@ MOPT_HD double solve_secular(const R &red, const double *w, const double *gt, in
         double fl, fpl = 0.0;
         if (cg2) {                                             // f and f' in one pass over the terms (same operations, two sums)
             double s0, s1;
-            red.sum2(m, [=](int i, double &a0, double &a1) { double dd = safe_den(cw[i] - lk, 1e-30); a0 += cg2[i] / dd; a1 += cg2[i] / (dd * dd); }, &s0, &s1);
+            red.sum2(m, [=](int i, double &a0, double &a1) { double dd = safe_den(cw[i] - lk, 1e-30); const double q = sec_quot(cg2[i], dd); a0 += q; a1 += sec_quot(q, dd); }, &s0, &s1);
             fl = lk + s0; fpl = 1.0 + s1;
         } else fl = secular_f(red, lk, w, gt, m, alpha, cg2, cw);
         if (fabs(fl) < tol) { if (iters) *iters = it + 1; return lk; }
