@@ -60,6 +60,10 @@ __device__ __forceinline__ int wave_min_int(int v) {
     return v;
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the acknowledgement of every global store still
+// in flight (1-2 us per step in the persistent tridiagonalisation kernels).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Block-wide sum of K values per thread; blockDim.x must be a multiple of 64 and <= 1024.
 // red must point to K * 16 doubles of LDS.  Result is returned to every thread.
 template <int K>

@@ -327,7 +327,7 @@ constexpr int TRI_FAIL_TIMEOUT = 1 << 16;
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits for the fabric
 // acknowledgement of every write-through store still in flight (1-2 us each step here); the exchange words need no such
 // ordering because each carries its own tag.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (lds_barrier: common.hpp)
 
 // thread layout: cols = roundup64(n) column threads x RG row groups (wave-uniform); one column per thread (n <= 1024)
 __global__ void __launch_bounds__(1024) k_tri_persist(int n, int G, int rows_cap, int cols, int RG, double *__restrict__ A_,
@@ -960,7 +960,9 @@ template <int CH, int TR, int NWV = 16>
 __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int rows_cap, double *__restrict__ A_, double *__restrict__ D_,
                                                        double *__restrict__ E_, double *__restrict__ TAU_, u64 *__restrict__ XCH_,
                                                        size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof, int nmat,
-                                                       int per_x, int try_local) {
+                                                       int per_x, int try_local, int k_last) {
+    // k_last = n - 3: the whole reduction.  k_last < n - 3: stop behind pivot row K = k_last + 1 and leave the rows below it (current up
+    // to the reflector of row K - 1) in A for k_tri_tail (k_tritail.hip), which finishes the block inside one compute unit.
     // MOPT_P3_RW0 = 1 makes wave 0 a pure communication wave (polls, prologue, no rows), back at the exchange right behind
     // the barrier instead of behind its own share of the main pass.  Measured on one box (n = 300, 32 matrices): 0.667 ms
     // against 0.640 ms with rows on all 16 waves -- the continuous polling costs more than the earlier start gains.
@@ -1277,7 +1279,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
         return true;
     };
-    for (; k <= n - 3; ++k) {
+    for (; k <= k_last; ++k) {
         const int lo3 = k + 1 - 3;                           // a chunk is skipped once it has been dead for three steps
         int qd = lo3 < 0 ? 0 : lo3 >> 6;
         if (qd > CH - 1) qd = CH - 1;
@@ -1297,7 +1299,25 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = 0; q[3] = t_main; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
     __syncthreads();
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], TRI_FAIL_TIMEOUT);      // (every s_fail of this kernel is a hand-off that timed out)
-    {
+    if (k_last < n - 3) {
+        // hand-over to k_tri_tail: the live rows (behind pivot row K) go back to A, all n columns of each (columns <= K are dead)
+        const int K = k_last + 1;
+        if constexpr (TR > 0) {
+#pragma unroll
+            for (int t = 0; t < TR; ++t) {
+                const int gi = gi_t[t];
+                if (gi > K) {
+#pragma unroll
+                    for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) A[(size_t)gi * n + jj] = areg[t][q]; }
+                }
+            }
+        } else {
+            for (int r = (wid >= RW0) ? wid - RW0 : r_end; r < r_end; r += NW) {
+                const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+                if (gi > K) for (int jj = lane; jj < n; jj += 64) A[(size_t)gi * n + jj] = Aloc[r * ns + jj];
+            }
+        }
+    } else {
         const int gi_last = n - 1;
         const int c = gi_last / TRI_RC;
         if (c % G == g && !s_fail) {
@@ -2048,6 +2068,9 @@ static const char *tri_env(const char *name) {
 bool mopt_bt_use_mfma(int n);
 int mopt_launch_bt_larft(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_A, const double *d_TAU, double *d_T);
 int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_TAU, const double *d_T, double *d_Vt, const int *d_bend, bool mfma);
+int mopt_tri_tail_max();
+int mopt_launch_tri_tail(mopt_ctx *ctx, hipStream_t st, int n, int K, int batch, double *d_A, double *d_D, double *d_E, double *d_TAU,
+                         long long *d_prof = nullptr);
 size_t mopt_dc_scratch_bytes(int n, int batch);
 int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_D, const double *d_E, int *d_flag, double *d_WT,
                    double *d_Vt, double *d_Z2, int *d_bstart, int *d_bend, int *d_fail, void *scratch);
@@ -2124,10 +2147,25 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const double t_step = fmax(10.0, (double)batch * n * n * 8.0 * 0.4 / 2.3e6);
         if (t_step < t_persist) persist2 = false;
     }
-    if (persist2 && want3) {
+    // Single-compute-unit route (k_tritail.hip): one workgroup per matrix, no cross-workgroup hand-off and hence no co-residency
+    // requirement.  Measured (profiles/r02s_tail_decision.txt): 1.2 us per Householder step at n = 64 but 2.0 us at n = 192 (one CU's FP64
+    // rate and the row reductions), against 1.6-2.0 us for k_tri_persist3 on 8 CUs whatever n: whole matrices go there up to n = 80
+    // (n = 42: 0.053 against 0.065 ms; n = 96: 0.153 against 0.141 ms; MOPT_TRI_TAILONLY=<n> moves the limit).  As the tail of a
+    // larger matrix (k_tri_persist3 stopped early, MOPT_TRI_TAILMAX=<rows>) it pays only where a persistent step is expensive: the
+    // 8-wave groups of n > 384 (3.0 us per step; n = 600: 3.91 -> 3.56 ms with a 128-row tail), not at n = 300 (0.61 ms either way).
+    const bool use_tail = multi && !(tri_env("MOPT_TRI_TAIL") && atoi(tri_env("MOPT_TRI_TAIL")) == 0);
+    const int tail_only = tri_env("MOPT_TRI_TAILONLY") ? std::min(atoi(tri_env("MOPT_TRI_TAILONLY")), mopt_tri_tail_max()) : 80;
+    const int tail_max = tri_env("MOPT_TRI_TAILMAX") ? std::min(atoi(tri_env("MOPT_TRI_TAILMAX")), mopt_tri_tail_max()) : (tr8 > 0 ? 128 : 0);
+    if (use_tail && n <= tail_only && !tri_env("MOPT_TRI_FORCEPERSIST")) {
+        mopt_scope sc(ctx, "eigh_tridiag", 1);
+        const int rc = mopt_launch_tri_tail(ctx, ctx->stream, n, -1, batch, d_A, d_D, d_E, d_TAU);
+        if (rc != MOPT_OK) return rc;
+    } else if (persist2 && want3) {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
         const int ch = (n + 63) / 64;
         const int G = G2;
+        int k_last = n - 3;
+        if (use_tail && tail_max >= 2 && n - tail_max - 2 >= -1) k_last = n - tail_max - 2;      // stop behind pivot row K = n - tail_max - 1
         int rows = rows_for(G);
         const int tr = (rows + 15 - MOPT_P3_RW0) / (16 - MOPT_P3_RW0);      // rows per row wave
         const void *fn = nullptr;
@@ -2184,8 +2222,12 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             size_t stride = (size_t)n * n;
             int *pF = d_fail + b0;
             long long *pP = d_prof ? d_prof + (size_t)b0 * G * 8 : nullptr;
-            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP, &nmat, &per_x, &try_local};
+            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP, &nmat, &per_x, &try_local, &k_last};
             MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(8 * per_x * G), dim3(nthreads), args, lds_use, ctx->stream));
+        }
+        if (k_last < n - 3) {
+            const int rc = mopt_launch_tri_tail(ctx, ctx->stream, n, k_last + 1, batch, d_A, d_D, d_E, d_TAU);
+            if (rc != MOPT_OK) return rc;
         }
         if (d_prof) {
             std::vector<long long> h((size_t)batch * G * 8);

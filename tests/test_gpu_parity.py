@@ -340,7 +340,8 @@ def test_rsprfo_traces_vs_reference():
 
 
 @pytest.mark.parametrize("algo", ["tridiag", "jacobi", "tridiag-stepwise", "tridiag-persistent", "tridiag-nosmall", "tridiag-persist2",
-                                  "tridiag-valubacktrans", "tridiag-group8", "tridiag-small32"])
+                                  "tridiag-valubacktrans", "tridiag-group8", "tridiag-small32", "tridiag-notail", "tridiag-tail192",
+                                  "tridiag-tail100w16", "tridiag-jacobismall"])
 def test_eigh_forced_route(ops, algo):
     """Both eigen-solvers forced for every size (MOPT_EIGH_ALGO): random, degenerate, clustered and LJ matrices.
     (By default the reduction route runs from n = 32 on and the Jacobi sweeps below.)"""
@@ -390,7 +391,12 @@ sys.exit(bad)
     extra = {"tridiag-stepwise": {"MOPT_TRI_NOPERSIST": "1"}, "tridiag-persistent": {"MOPT_TRI_FORCEPERSIST": "1"},
              "tridiag-nosmall": {"MOPT_TRI_SMALL": "0"}, "tridiag-persist2": {"MOPT_TRI_P3": "0"},
              "tridiag-valubacktrans": {"MOPT_BT_MFMA": "0"}, "tridiag-group8": {"MOPT_TRI_GMAX": "8"},
-             "tridiag-small32": {"MOPT_TRI_SMALL": "32"}}.get(algo, {})
+             "tridiag-small32": {"MOPT_TRI_SMALL": "32"}, "tridiag-notail": {"MOPT_TRI_TAIL": "0"},
+             # single-compute-unit tridiagonalisation (k_tritail.hip): whole matrices up to n = 192, and as the 192- / 100-row tail of
+             # the persistent kernel for n = 300 (8- and 16-wave forms of the three-chunk kernel)
+             "tridiag-tail192": {"MOPT_TRI_TAILONLY": "192", "MOPT_TRI_TAILMAX": "192"},
+             "tridiag-tail100w16": {"MOPT_TRI_TAILONLY": "192", "MOPT_TRI_TAILMAX": "100", "MOPT_TAIL_W8": "0"},
+             "tridiag-jacobismall": {"MOPT_TRI_QL": "0"}}.get(algo, {})
     env = dict(os.environ, MOPT_EIGH_ALGO=algo.split("-")[0], **extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     print(r.stdout)
