@@ -16,7 +16,8 @@ import copy
 import numpy as np
 
 from .optimizer import CalculateMoveVector, BOHR2ANGSTROMS
-from .Utils.calc_tools import Calculationtools
+from .Utils.calc_tools import Calculationtools, apply_climbing_image
+from .Interpolation.linear_interpolation import distribute_geometry
 
 
 def quantise_xyz(x_ang):
@@ -163,14 +164,16 @@ def make_band(frames_ang, partition):
 
 def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
                   ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999, devices=None,
-                  transport="rccl", model_hessian=None, MFC_COUNT=50):
+                  transport="rccl", model_hessian=None, MFC_COUNT=50, align_distances=0, climbing_image=(999999, 999999)):
     """Band relaxation as in nebmain: with FC_COUNT != -1 the Hessian-based branch (`-fc`: RFOOptimizer on a BNEB force),
     otherwise the default FIRE optimizer, replaced by steepest descent from iteration `steepest_descent` on (`-sd`,
     neb.py:794-804, 939-948).
     `engine.calculate(X_ang (I,N,3), optimize_num)` -> (E (I,), G (I,N,3), X_bohr (I,N,3), hessians | None) is the in-memory
     form of the reference's Engine.calculate and its tmp_hessian_i.npy side channel.  Per iteration, in the reference's order
     (neb.py:497-597): energies/gradients -> BNEB force -> RFOOptimizer.optimize (which recomputes the force, rfo_neb.py:131)
-    -> edge fixing -> sequential Kabsch k -> k+1 (centres image k+1 in place) -> `%17.12f` quantisation."""
+    -> climbing-image move when due (`-ci start interval`, neb.py:561-564) -> edge fixing -> sequential Kabsch k -> k+1 (centres image
+    k+1 in place) -> equal-arc-length re-distribution every `align_distances` iterations (`-ad`, neb.py:649-766; the other
+    `-ad*` strategies are not built) -> `%17.12f` quantisation."""
     from .MEP.pathopt_bneb_force import CaluculationBNEB
     from .Optimizer.rfo_neb import RFOOptimizer
     from .Optimizer.fire_neb import FIREOptimizer
@@ -223,6 +226,9 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
             new_geometry = SteepestDescentOptimizer(config).optimize(X, total_force)
         new_geometry = np.array(new_geometry, dtype="float64")
         opt_out = new_geometry.copy() if record is not None else None
+        ci_start, ci_interval = climbing_image
+        if optimize_num > ci_start and (optimize_num - ci_start) % ci_interval == 0:
+            new_geometry = np.array(apply_climbing_image(list(new_geometry), E, element_list), dtype="float64")
         # NEB._apply_constraints (neb.py:966-998), no fixed atoms
         if config.fix_init_edge:
             new_geometry[0] = init_geometry[0] * BOHR2ANGSTROMS
@@ -231,6 +237,8 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
         for k in range(len(new_geometry) - 1):
             aligned, _ = tools.kabsch_algorithm(new_geometry[k], new_geometry[k + 1])
             new_geometry[k] = copy.copy(aligned)
+        if optimize_num > 0 and align_distances >= 1 and optimize_num % align_distances == 0:      # NEB._align_geometries
+            new_geometry = np.array(distribute_geometry(np.array(new_geometry)), dtype="float64")
         if record is not None:
             record.append(dict(E=E.copy(), G=G.copy(), X=X.copy(), opt=opt_out, post=new_geometry.copy(),
                                hess=[optimizer.get_image_hessian(i) for i in range(len(X))] if rfo_branch else [],

@@ -797,9 +797,54 @@ def _run_nebmain(tag, N, argv, out):
     print("G8 neb", tag, "iterations:", nit, "images:", calc_rec[0][0].shape[0])
 
 
+def g13_path_tools():
+    """G13: the path tools nebmain calls between the optimizer and the next input files (neb.py:561-572): calc_path_length_list,
+    distribute_geometry (`-ad`), the natural-spline extrema and the IDPP objective / gradient / three-image relaxation behind
+    apply_climbing_image (`-ci`), and apply_climbing_image itself on a 10-image Ar7 band with a synthetic two-barrier profile."""
+    from multioptpy.Utils import calc_tools as ct
+    from multioptpy.Interpolation import linear_interpolation as li
+    from multioptpy.Interpolation import interpolation as ip
+    from multioptpy.Potential import idpp as idpp_mod
+    out = {}
+    rng = np.random.default_rng(13)
+    X = cases.band(10, 7) * cases.BOHR2ANG
+    X = X + 0.05 * rng.normal(size=X.shape)
+    out["X"] = X
+    out["path_length"] = np.array(ct.calc_path_length_list(list(X)))
+    out["distributed"] = np.array(li.distribute_geometry(list(X)))
+    # uneven band: two images close together, one far apart
+    Xu = X.copy()
+    Xu[3] = 0.9 * Xu[2] + 0.1 * Xu[4]
+    Xu[6] = 0.2 * Xu[5] + 0.8 * Xu[7]
+    out["Xu"] = Xu
+    out["distributed_u"] = np.array(li.distribute_geometry(list(Xu)))
+    E = np.array([0.0, 0.004, 0.011, 0.019, 0.013, 0.009, 0.015, 0.012, 0.005, 0.001])
+    out["E"] = E
+    with quiet():
+        mx, mn = ip.spline_interpolation(out["path_length"], E)
+    out["spline_max"] = np.array(mx, dtype=float).reshape(-1, 2)
+    out["spline_min"] = np.array(mn, dtype=float).reshape(-1, 2)
+    inst = idpp_mod.IDPP()
+    trio = [X[3].copy(), 0.4 * X[3] + 0.6 * X[4] + 0.03 * rng.normal(size=X[3].shape), X[4].copy()]
+    out["trio"] = np.array(trio)
+    f, g = inst.get_func_and_deriv(trio, 3, 1)
+    out["idpp_obj"], out["idpp_grad"] = np.array(f), np.array(g)
+    with quiet():
+        rel = idpp_mod.IDPP().opt_path([t.copy() for t in trio], ["Ar"] * 7)
+    out["idpp_relaxed"] = np.array(rel)
+    with quiet():
+        ci = ct.apply_climbing_image([x.copy() for x in X], list(E), ["Ar"] * 7)
+    out["ci_out"] = np.array(ci)
+    np.savez_compressed(os.path.join(HERE, "g13_path_tools.npz"), **out)
+    moved = [i for i in range(len(X)) if np.abs(out["ci_out"][i] - X[i]).max() > 0]
+    print("G13 written; spline maxima:", out["spline_max"][:, 0], "images moved by the climbing-image step:", moved)
+
+
 def g8_nebmain():
     """G8 (NEB half): the reference's nebmain loop on an Ar7 band, RFO branch, exact Hessians every 3 iterations."""
     out = {}
+    _run_nebmain("a", 7, ["-fc", "3", "-ns", "5", "-p", "5", "-ad", "2"], out)         # images re-distributed on iterations 2 and 4
+    _run_nebmain("c", 7, ["-fc", "3", "-ns", "5", "-p", "5", "-ci", "1", "2"], out)    # climbing-image move on iteration 3
     _run_nebmain("n", 7, ["-fc", "3", "-ns", "5", "-p", "5"], out)
     _run_nebmain("e", 7, ["-fc", "2", "-ns", "4", "-p", "5", "-fe", "3"], out)
     _run_nebmain("f", 7, ["-ns", "9", "-p", "5"], out)                       # FIRE branch (the default optimizer of nebmain)
@@ -809,7 +854,9 @@ def g8_nebmain():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g11", "g12", "g13"]
+    if "g13" in which:
+        g13_path_tools()
     if "g1" in which:
         g1_updates()
     if "g2" in which:

@@ -506,7 +506,7 @@ def test_optmain_driver_vs_reference(tag):
     print("optmain", tag, "worst move-vector deviation from the reference", worst)
 
 
-@pytest.mark.parametrize("tag", ["n", "e", "f", "s"])
+@pytest.mark.parametrize("tag", ["n", "e", "f", "s", "a", "c"])
 def test_nebmain_driver_vs_reference(tag):
     """a23: the in-memory nebmain iteration (RFO branch) on the device path against the reference driver's own band
     trajectory (G8): geometry read by the engine, optimizer output, geometry after edge fixing + Kabsch chain, Hessians."""
@@ -515,9 +515,9 @@ def test_nebmain_driver_vs_reference(tag):
     from multioptpy_amd import drivers
     from test_oracle_golden import _check_nebmain
 
-    def run(ends, fc, nstep, p, fe, rec, sd):
+    def run(ends, fc, nstep, p, fe, rec, sd, **extra):          # extra: align_distances (`-ad`), climbing_image (`-ci`)
         eng = cases.LJEngine(FC_COUNT=fc, project=pj.project_hessian_trrot)           # the engine is upstream of the path
-        drivers.nebmain_steps(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, steepest_descent=sd)
+        drivers.nebmain_steps(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, steepest_descent=sd, **extra)
 
     worst = _check_nebmain(run, np.load(os.path.join(G, "g8_nebmain.npz")), tag, 1e-8)
     print("nebmain", tag, "worst optimizer-output deviation from the reference", worst)

@@ -297,7 +297,12 @@ def _check_nebmain(run, z, tag, tol):
     ends = z[tag + "_ends_bohr"] * cases.BOHR2ANG
     ends = np.array([[[float(f"{v:.10f}") for v in r] for r in x] for x in ends])       # the start files hold 10 decimals
     rec = []
-    run(ends, fc, nstep, p, fe, rec, sd)
+    extra = {}
+    if "-ad" in argv:
+        extra["align_distances"] = int(argv[argv.index("-ad") + 1])
+    if "-ci" in argv:
+        extra["climbing_image"] = (int(argv[argv.index("-ci") + 1]), int(argv[argv.index("-ci") + 2]))
+    run(ends, fc, nstep, p, fe, rec, sd, **extra)
     assert len(rec) == int(z[tag + "_nit"])
     worst = 0.0
     for k, r in enumerate(rec):
@@ -316,15 +321,15 @@ def _check_nebmain(run, z, tag, tol):
     return worst
 
 
-@pytest.mark.parametrize("tag", ["n", "e", "f", "s"])
+@pytest.mark.parametrize("tag", ["n", "e", "f", "s", "a", "c"])
 def test_g8_nebmain_driver(tag):
-    """a23: the oracle's in-memory nebmain iteration (RFO branch; FIRE branch; FIRE then steepest descent) against the
-    reference driver's own band trajectory."""
+    """a23: the oracle's in-memory nebmain iteration (RFO branch; FIRE branch; FIRE then steepest descent; RFO branch with image
+    re-distribution `-ad 2` and with the climbing-image move `-ci 1 2`) against the reference driver's own band trajectory."""
     from oracle import driver
 
-    def run(ends, fc, nstep, p, fe, rec, sd):
+    def run(ends, fc, nstep, p, fe, rec, sd, **extra):
         eng = cases.LJEngine(FC_COUNT=fc, project=pj.project_hessian_trrot)
-        driver.run_nebmain(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, literal=True, sd_from=sd)
+        driver.run_nebmain(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, literal=True, sd_from=sd, **extra)
 
     worst = _check_nebmain(run, np.load(os.path.join(G, "g8_nebmain.npz")), tag, 1e-9)
     print("nebmain", tag, "worst optimizer-output deviation", worst)
@@ -416,3 +421,42 @@ def test_g12_constraint_host_parts_of_the_plugin_class():
     assert np.abs(pc.adjust_init_coord(z["shake_in"].copy()) - z["shake_out"]).max() < 1e-13
     with pytest.raises(NotImplementedError):
         ProjectOutConstrain(["rot"], [[1, 2, 3]])
+
+
+def test_g13_path_tools_oracle_and_host_glue_vs_reference():
+    """G13: path length, equal-arc-length re-distribution, natural-spline extrema, IDPP objective / gradient / three-image relaxation
+    and the climbing-image move -- the oracle's loops AND the package's host glue (numpy on (I, N, 3) arrays, as in the reference;
+    no device code involved) against the reference's outputs."""
+    from oracle import path_tools as pt
+    from multioptpy_amd.Utils.calc_tools import calc_path_length_list, apply_climbing_image
+    from multioptpy_amd.Interpolation.linear_interpolation import distribute_geometry
+    from multioptpy_amd.Interpolation.interpolation import spline_interpolation
+    from multioptpy_amd.Potential.idpp import IDPP
+    z = np.load(os.path.join(G, "g13_path_tools.npz"))
+    X, Xu, E = z["X"], z["Xu"], z["E"]
+    for f in (pt.path_lengths, calc_path_length_list):
+        assert np.abs(np.array(f(list(X))) - z["path_length"]).max() < 1e-14
+    for f in (pt.redistribute, distribute_geometry):
+        assert np.abs(np.array(f(list(X))) - z["distributed"]).max() < 1e-13
+        assert np.abs(np.array(f(list(Xu))) - z["distributed_u"]).max() < 1e-13
+    for f in (pt.spline_extrema, spline_interpolation):
+        mx, mn = f(z["path_length"], E)
+        assert np.abs(np.array(mx).reshape(-1, 2) - z["spline_max"]).max() < 1e-12
+        assert np.abs(np.array(mn).reshape(-1, 2) - z["spline_min"]).max() < 1e-12
+    trio = [t.copy() for t in z["trio"]]
+    for f in (lambda im: pt.idpp_value_gradient(im, 1), lambda im: IDPP().get_func_and_deriv(im, 3, 1)):
+        val, grad = f(trio)
+        assert abs(val - float(z["idpp_obj"])) < 1e-12 * max(1.0, abs(float(z["idpp_obj"])))
+        assert np.abs(grad - z["idpp_grad"]).max() < 1e-12 * max(1.0, np.abs(z["idpp_grad"]).max())
+    rel_o = pt.idpp_relax([t.copy() for t in z["trio"]])
+    rel_p = IDPP().opt_path([t.copy() for t in z["trio"]], ["Ar"] * 7)
+    print("IDPP relaxation: oracle", np.abs(np.array(rel_o) - z["idpp_relaxed"]).max(), "package", np.abs(np.array(rel_p) - z["idpp_relaxed"]).max())
+    assert np.abs(np.array(rel_o) - z["idpp_relaxed"]).max() < 1e-9
+    assert np.abs(np.array(rel_p) - z["idpp_relaxed"]).max() < 1e-9
+    ci_o = pt.climbing_image_move(list(X), E)
+    ci_p = apply_climbing_image([x.copy() for x in X], list(E), ["Ar"] * 7)
+    moved = [i for i in range(len(X)) if np.abs(z["ci_out"][i] - X[i]).max() > 0]
+    assert moved == [3, 6]
+    print("climbing-image move: oracle", np.abs(np.array(ci_o) - z["ci_out"]).max(), "package", np.abs(np.array(ci_p) - z["ci_out"]).max())
+    assert np.abs(np.array(ci_o) - z["ci_out"]).max() < 1e-9
+    assert np.abs(np.array(ci_p) - z["ci_out"]).max() < 1e-9
