@@ -20,6 +20,9 @@ struct mopt_band {
     bool have_vecs = false;          // wk.Vt holds the eigenvectors of the previous step (warm start)
     int warm_run = 0;                // consecutive warm-started solves (a cold solve every 64 re-orthogonalises V)
     int warm_enabled = 1;
+    bool fused_step = false;         // this step takes the fused path (decided in phase a, where the TR/rot basis is forked)
+    std::vector<char> H_sym;         // per owned image: the resident Hessian is known to be bitwise symmetric (identity, model Hessian,
+                                     // a symmetric upload): the band then takes the fused update + projection path (k_fused.hip)
     std::vector<double> hE;
     // ---- image-sharded band with an exchange layer (comm.hip): this object owns images [first, first + count) and holds
     // the neighbours' boundary images (X, G) and all energies after mopt_halo_exchange

@@ -264,6 +264,7 @@ int mopt_band_alloc_internal(mopt_band *b) {
         MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + (size_t)k * b->n * b->n, eye.data(), eye.size() * 8, hipMemcpyHostToDevice, ctx->stream));
     MOPT_HIP_TRY(ctx, hipMemsetAsync(b->wk.be, 0, (size_t)b->count * 8, ctx->stream));     // OPT.run(..., 0.0, 0.0, ...) (rfo_neb.py:166)
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->H_sym.assign((size_t)b->count, 1);
     b->alloc_done = true;
     return MOPT_OK;
 }
@@ -323,8 +324,25 @@ extern "C" int mopt_band_set_hessian(mopt_band *b, int image, const double *H) {
     mopt_ctx *ctx = b->ctx;
     const size_t nn = (size_t)b->n * b->n;
     if (H) {
-        MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + loc * nn, H, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+        // The kernels of the update (u = H s stands for s^T H as well) assume a symmetric matrix; the reference would carry an unsymmetric
+        // one as it is until its first update (rsirfo.py:1368-1372).  An upload that is not bitwise symmetric is therefore replaced by
+        // 0.5 (H + H^T) here: results then differ from the reference's by O(asymmetry) -- as they did with the matrix kept as it was.
+        bool sym = true;
+        for (int i = 0; i < b->n && sym; ++i)
+            for (int j = 0; j < i; ++j)
+                if (std::memcmp(&H[(size_t)i * b->n + j], &H[(size_t)j * b->n + i], 8) != 0) { sym = false; break; }
+        if (sym) {
+            MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + loc * nn, H, nn * 8, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            std::vector<double> hs(nn);
+            for (int i = 0; i < b->n; ++i)
+                for (int j = 0; j <= i; ++j) { const double v = 0.5 * (H[(size_t)i * b->n + j] + H[(size_t)j * b->n + i]); hs[(size_t)i * b->n + j] = v; hs[(size_t)j * b->n + i] = v; }
+            MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + loc * nn, hs.data(), nn * 8, hipMemcpyHostToDevice, ctx->stream));
+            MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        b->H_sym[loc] = 1;
     } else {
+        b->H_sym[loc] = 1;
         std::vector<double> eye(nn, 0.0);
         for (int i = 0; i < b->n; ++i) eye[(size_t)i * b->n + i] = 1.0;
         MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.H + loc * nn, eye.data(), nn * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -436,6 +454,15 @@ int mopt_band_step_phase_a(mopt_band *b, int optimize_num) {
         b->have_vecs = false;
     }
     const bool have_prev = b->have_prev && optimize_num != 0;
+    // fused update + projection (k_fused.hip) when every owned Hessian is known to be bitwise symmetric; MOPT_BAND_FUSED=0: unfused chain.
+    // Its first kernel needs the TR/rot basis of the new geometries: forked onto the side stream here, ahead of the force kernel.
+    {
+        static const bool fused_env = !(getenv("MOPT_BAND_FUSED") && atoi(getenv("MOPT_BAND_FUSED")) == 0);
+        bool fused = fused_env;
+        for (char c : b->H_sym) fused = fused && c;
+        b->fused_step = fused;
+        if (fused) BTRY(mopt_launch_trrot_basis_side(ctx, n, count, b->X + (size_t)first * n, wk.Q));
+    }
     // (a fill node, not a copy from a host buffer: the step enqueues without waiting for the stream)
     MOPT_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)wk.do_update, have_prev ? 1 : 0, (size_t)count, ctx->stream));
     // 1. NEB force.  Whole band on one device: all images (FIRE's switch sums over all of F).  Image-sharded: the owned images;
@@ -462,17 +489,19 @@ int mopt_band_step_phase_b(mopt_band *b, int optimize_num) {
     const bool sharded = (b->comm != nullptr);
     const bool have_prev = b->have_prev && optimize_num != 0;
     // 2. Ayala curvature correction of the owned interior images
+    const bool fused = b->fused_step;
     {
-        mopt_scope sc(ctx, "neb_ayala", 2);
+        mopt_scope sc(ctx, "neb_ayala", fused ? 1 : 2);
         hipLaunchKernelGGL(k_gamma, dim3(count), dim3(256), 0, ctx->stream, I, n, first, b->X, b->E, b->G, b->tau, b->gamma);
-        hipLaunchKernelGGL(k_rank1, dim3((n + 7) / 8, count), dim3(256), 0, ctx->stream, n, first, b->gamma, b->tau, wk.H);
+        if (!fused) hipLaunchKernelGGL(k_rank1, dim3((n + 7) / 8, count), dim3(256), 0, ctx->stream, n, first, b->gamma, b->tau, wk.H);
     }
+    const mopt::FusedBand fb = {b->gamma, b->tau, first};
     // 3. per-image RSIRFO.run with B_g = g = biased gradient, energies 0.0 (rfo_neb.py:159-166)
     double *sx = wk.x, *sbg = wk.bg, *sg = wk.g, *spx = wk.px, *spg = wk.pg;
     wk.x = b->X + (size_t)first * n; wk.bg = b->G + (size_t)first * n; wk.g = wk.bg;
     wk.px = b->pX + (size_t)first * n; wk.pg = b->pG + (size_t)first * n;
     const bool warm = b->warm_enabled && b->have_vecs && b->warm_run < 64;
-    int rc = mopt_rsirfo_pipeline(ctx, wk, n, count, have_prev, false, nullptr, wk.H, warm);
+    int rc = mopt_rsirfo_pipeline(ctx, wk, n, count, have_prev, false, nullptr, wk.H, warm, fused ? &fb : nullptr);
     b->warm_run = warm ? b->warm_run + 1 : 0;
     b->have_vecs = true;
     b->stepped = true;
@@ -512,9 +541,13 @@ extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par
     hipError_t e = hipMemcpyAsync(d_par, par, (size_t)4 * b->N * 8, hipMemcpyHostToDevice, ctx->stream);
     int rc = (e == hipSuccess) ? mopt_launch_model_hessian(ctx, b->N, b->count, b->X + (size_t)b->first * b->n, d_par, d3, b->wk.Gt, b->wk.Q, b->wk.W6, b->wk.H, true)
                                : MOPT_E_DEVICE;
+    // the projection's rank-12 correction is symmetric only up to rounding (a q w + w q pair is folded into an FMA): one in-place
+    // 0.5 (H + H^T) makes the resident matrices bitwise symmetric -- what an upload of the same matrices would store, see mopt_band_set_hessian
+    if (rc == MOPT_OK) rc = mopt_launch_sym_add(ctx, b->n, b->count, b->wk.H, nullptr, b->wk.H);
     hipStreamSynchronize(ctx->stream);
     hipFree(d_par);
     b->have_vecs = false;
+    b->H_sym.assign((size_t)b->count, 1);
     return rc;
 }
 

@@ -60,6 +60,35 @@ __device__ __forceinline__ int wave_min_int(int v) {
     return v;
 }
 
+// ---- four sums at once (gfx950: v_permlane32_swap, v_permlane16_swap)
+__device__ __forceinline__ void swap_halves(double &a, double &b) {        // a[32..63] <-> b[0..31]
+    auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+__device__ __forceinline__ void swap_rows(double &a, double &b) {          // odd 16-lane rows of a <-> even rows of b
+    auto r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+// Sums over the 64 lanes of four values at once.  Result: every lane of 16-lane row 0 holds sum(d0), row 1 sum(d2), row 2 sum(d1),
+// row 3 sum(d3).
+__device__ __forceinline__ double wave_sum4(double d0, double d1, double d2, double d3) {
+    swap_halves(d0, d1);
+    swap_halves(d2, d3);
+    double e0 = d0 + d1;                    // lanes 0..31: d0 (lane + lane+32), lanes 32..63: d1
+    double e1 = d2 + d3;                    // lanes 0..31: d2, lanes 32..63: d3
+    swap_rows(e0, e1);
+    double f = e0 + e1;                     // rows: d0, d2, d1, d3 (16 partial sums each)
+    f += dpp_f64z<0xB1>(f);                 // quad_perm [1,0,3,2]
+    f += dpp_f64z<0x4E>(f);                 // quad_perm [2,3,0,1]
+    f += dpp_f64z<0x141>(f);                // row_half_mirror
+    f += dpp_f64z<0x140>(f);                // row_mirror
+    return f;
+}
+
 // Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the acknowledgement of every global store still
 // in flight (1-2 us per step in the persistent tridiagonalisation kernels).
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -75,6 +104,28 @@ __device__ __forceinline__ void block_sum(double (&v)[K], double *red) {
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < K; ++k) red[k * 16 + wid] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        double a = 0.0;
+        for (int w = 0; w < nw; ++w) a += red[k * 16 + w];
+        v[k] = a;
+    }
+}
+
+// The same with the wave-level sums taken four at a time (wave_sum4: 21 instructions per four values instead of 4 x 20).
+// K is rounded up to a multiple of four internally; red: ((K + 3) / 4) * 4 * 16 doubles.
+template <int K>
+__device__ __forceinline__ void block_sum_x4(double (&v)[K], double *red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    constexpr int G = (K + 3) / 4;
+    __syncthreads();                       // protect red[] from a previous use
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const double a0 = v[4 * g], a1 = (4 * g + 1 < K) ? v[4 * g + 1] : 0.0, a2 = (4 * g + 2 < K) ? v[4 * g + 2] : 0.0, a3 = (4 * g + 3 < K) ? v[4 * g + 3] : 0.0;
+        const double f = wave_sum4(a0, a2, a1, a3);          // 16-lane rows 0 .. 3 hold the sums of a0, a1, a2, a3
+        if ((lane & 15) == 0) red[(4 * g + (lane >> 4)) * 16 + wid] = f;
     }
     __syncthreads();
 #pragma unroll

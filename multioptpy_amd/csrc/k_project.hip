@@ -73,8 +73,8 @@ __global__ void __launch_bounds__(256) k_trrot_basis(int n, const double *__rest
 }
 
 // A = 0.5 ((H+B) + (H+B)^T); tile pairs as in k_apply_update.  Bias may be null.
-__global__ void __launch_bounds__(256) k_sym_add(int n, const double *__restrict__ H, const double *__restrict__ Bias,
-                                                 double *__restrict__ A) {
+// A may be H itself (in place: a tile pair is read completely before it is written).
+__global__ void __launch_bounds__(256) k_sym_add(int n, const double *H, const double *__restrict__ Bias, double *A) {
     __shared__ double L[32][33], S[32][33];
     const int T = (n + 31) / 32;
     const int bi = blockIdx.x / T, bj = blockIdx.x % T;

@@ -23,34 +23,6 @@
 
 namespace mopt {
 
-__device__ __forceinline__ void swap_halves(double &a, double &b) {        // a[32..63] <-> b[0..31]
-    auto r0 = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    auto r1 = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-__device__ __forceinline__ void swap_rows(double &a, double &b) {          // odd 16-lane rows of a <-> even rows of b
-    auto r0 = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
-    auto r1 = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
-    a = __hiloint2double((int)r1[0], (int)r0[0]);
-    b = __hiloint2double((int)r1[1], (int)r0[1]);
-}
-// Sums over the 64 lanes of four values at once.  Result: every lane of 16-lane row 0 holds sum(d0), row 1 sum(d2), row 2 sum(d1),
-// row 3 sum(d3).
-__device__ __forceinline__ double wave_sum4(double d0, double d1, double d2, double d3) {
-    swap_halves(d0, d1);
-    swap_halves(d2, d3);
-    double e0 = d0 + d1;                    // lanes 0..31: d0 (lane + lane+32), lanes 32..63: d1
-    double e1 = d2 + d3;                    // lanes 0..31: d2, lanes 32..63: d3
-    swap_rows(e0, e1);
-    double f = e0 + e1;                     // rows: d0, d2, d1, d3 (16 partial sums each)
-    f += dpp_f64z<0xB1>(f);                 // quad_perm [1,0,3,2]
-    f += dpp_f64z<0x4E>(f);                 // quad_perm [2,3,0,1]
-    f += dpp_f64z<0x141>(f);                // row_half_mirror
-    f += dpp_f64z<0x140>(f);                // row_mirror
-    return f;
-}
-
 // 1 / sqrt(x) and 1 / x for normal x of moderate size: hardware estimate + two Newton steps (a few ulp)
 __device__ __forceinline__ double tail_rsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);

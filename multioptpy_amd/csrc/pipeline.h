@@ -36,9 +36,15 @@ struct RsirfoWork {
     ~RsirfoWork();
 };
 
+// Band path, fused form (k_fused.hip): Ayala term gamma t t^T, quasi-Newton update and TR/rot projection in three launches.
+namespace mopt { struct FusedBand { const double *gamma; const double *tau; int first; }; }
+int mopt_launch_fused_update_project(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, const mopt::FusedBand &fb);
+
 // update (optional) -> TR/rot projections -> eigh -> RS-I-RFO step.  Hsym may alias wk.H (in-place).
+// fb != null: the caller guarantees bitwise symmetric Hessians in wk.H (= Hsym), no bias, no flowchart rule; the Ayala term is then
+// applied here and not by the caller.
 int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
-                         double *d_Hinpl, double *d_Hsym, bool warm_eigh = false);
+                         double *d_Hinpl, double *d_Hsym, bool warm_eigh = false, const mopt::FusedBand *fb = nullptr);
 
 // launchers (defined next to their kernels)
 int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules, const int *d_do_update, bool any_flowchart,

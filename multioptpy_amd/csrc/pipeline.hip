@@ -50,21 +50,29 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
 }
 
 int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
-                         double *d_Hinpl, double *d_Hsym, bool warm_eigh) {
+                         double *d_Hinpl, double *d_Hsym, bool warm_eigh, const mopt::FusedBand *fb) {
     int rc;
     const mopt::UpdateCoef *coef = nullptr;
-    rc = mopt_launch_trrot_basis_side(ctx, n, batch, wk.x, wk.Q);                                    // joined in front of k_proj_w
-    if (rc != MOPT_OK) return rc;
+    if (!fb) {                                               // (fused band path: already forked by the band, ahead of its force kernel)
+        rc = mopt_launch_trrot_basis_side(ctx, n, batch, wk.x, wk.Q);                                // joined in front of k_proj_w
+        if (rc != MOPT_OK) return rc;
+    }
     rc = mopt_launch_project_grad(ctx, n, batch, wk.bg, wk.x, wk.gp, 0, /*side_stream=*/true);      // joined in front of the RFO stage
     if (rc != MOPT_OK) return rc;
-    if (any_update) {
+    if (fb) {
+        rc = mopt_launch_fused_update_project(ctx, wk, n, batch, *fb);
+        if (rc != MOPT_OK) return rc;
+        coef = wk.coef;
+    } else if (any_update) {
         rc = mopt_launch_hess_update(ctx, n, batch, wk.rules, wk.do_update, any_flowchart, wk.x, wk.px, wk.g, wk.pg, wk.s, wk.y,
                                      wk.u, wk.Hy, wk.yd, wk.Av, wk.coef, wk.info, wk.H, d_Hinpl, d_Hsym, false);
         if (rc != MOPT_OK) return rc;
         coef = wk.coef;
     }
-    rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A, /*basis_ready=*/true);
-    if (rc != MOPT_OK) return rc;
+    if (!fb) {
+        rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A, /*basis_ready=*/true);
+        if (rc != MOPT_OK) return rc;
+    }
     rc = mopt_eigh_auto(ctx, wk, n, batch, warm_eigh, /*preserve_A=*/false);
     if (rc != MOPT_OK) return rc;
     MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));       // the projected gradient (side stream)

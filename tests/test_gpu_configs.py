@@ -18,10 +18,13 @@ def _oracle_band_steps(X0, nsteps, hessians=None):
     return f(X0, nsteps, literal=False, hessians=hessians)
 
 
-def _run_band(I, N, nsteps, exact, tol=1e-8):
+def _run_band(I, N, nsteps, exact, tol=1e-8, skew=0.0):
     from multioptpy_amd.band import Band
     X0 = cases.band(I, N)
     hess = [cases.lj(X0[i], hessian=True)[2] for i in range(I)] if exact else None
+    if skew:                                                  # deliberately unsymmetric Hessians (e.g. finite-difference ones)
+        rng = np.random.default_rng(5)
+        hess = [h + skew * rng.normal(size=h.shape) for h in hess]
     band = Band(I, N)
     if exact:
         for i in range(I):
@@ -44,6 +47,34 @@ def test_band_16x14_vs_oracle(exact):
     """BASELINE config 4's shape (16-image band of a 14-atom system, n = 42): five consecutive steps."""
     worst, _ = _run_band(16, 14, 5, exact)
     print("16 x 14 band, exact Hessian start" if exact else "16 x 14 band, identity start", "worst deviation", worst)
+
+
+def test_band_fused_chain_matches_unfused_and_unsymmetric_upload():
+    """The fused update + projection (k_fused.hip) against the kernel-per-operation chain (MOPT_BAND_FUSED=0), and an upload that is
+    not bitwise symmetric: the band stores 0.5 (H + H^T) (the update kernels take u = H s for s^T H as well), so results differ from
+    the reference's -- which carries the unsymmetric matrix until its first update -- by O(asymmetry) (x 1e3 on this surface: an
+    asymmetry of 1e-13 shows up as 1e-10 in the geometries; 1e-11 already reaches the 1e-8 tolerance)."""
+    import os
+    import subprocess
+    import sys
+    worst, Hd = _run_band(8, 14, 4, True, skew=1e-13)
+    assert np.array_equal(Hd, Hd.T)
+    print("upload with an asymmetry of 1e-13: worst deviation from the oracle", worst)
+    code = ("import sys, os; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests')); "
+            "sys.path.insert(0, os.path.join(os.getcwd(), 'tests', 'golden')); import numpy as np, test_gpu_configs as t; "
+            "w, H = t._run_band(16, 14, 5, True); np.save(sys.argv[1], H); print(w)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for fused in ("1", "0"):
+        f = os.path.join("/tmp", f"mopt_fused_{fused}_{os.getpid()}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MOPT_BAND_FUSED=fused), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+        os.remove(f)
+    d = np.abs(outs[0] - outs[1]).max()
+    print("fused vs unfused chain, Hessian of the middle image after five steps:", d)
+    assert d < 1e-12
+    assert np.array_equal(outs[0], outs[0].T)                 # the fused path keeps the resident Hessians bitwise symmetric
 
 
 def test_band_64x200_vs_oracle():
