@@ -134,7 +134,7 @@ def cpu_baseline(traj, I, N, budget_s=25.0, hess0=None):
 
 
 FAMILIES = ("hess_update", "project", "eigh_init", "eigh_jacobi", "eigh_tridiag", "eigh_bisect", "eigh_invit", "eigh_backtrans",
-            "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post", "halo", "eigh_dc")
+            "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post", "halo", "eigh_dc", "rfo_scalar", "eigh_small", "eigh_early", "apply_qt", "larft")
 # algorithmic bytes per image-step of a family in units of n^2 (80 n^2 for the whole RSIRFO.run, of which the
 # eigen-solve's share is input read + eigenvector write; reduction route: the tridiagonalisation reads the matrix once (8 n^2)
 # and leaves the reflectors in its strict upper triangle (4 n^2); the back-transformation reads reflectors + eigenvectors and
@@ -266,6 +266,8 @@ def main():
             b2 = fresh()
             run(b2, timing=(rank == 0))
             if rank == 0:
+                if os.environ.get("MOPT_TIMELINE"):
+                    b2.timing_read("timeline")
                 for name in FAMILIES:
                     ms, nl = b2.timing_read(name)
                     fam[name] = {"ms_per_step": ms / K, "launches_per_step": nl / K}

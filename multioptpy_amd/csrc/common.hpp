@@ -178,6 +178,7 @@ struct mopt_ctx {
     hipEvent_t ev_fork4 = nullptr, ev_join4 = nullptr;
     hipStream_t side3 = nullptr;             // third helper stream (divide-and-conquer chain of the eigen-solver)
     hipEvent_t ev_fork5 = nullptr, ev_join5 = nullptr;
+    hipEvent_t ev_fork6 = nullptr, ev_join6 = nullptr;   // scalar RFO stage next to the back-transformation (pipeline.hip)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_fork3 = nullptr, ev_join3 = nullptr;
     std::string err;
     bool timing = false;
@@ -185,6 +186,8 @@ struct mopt_ctx {
     int lds_limit = 65536;
     int num_cu = 256;
     bool tri_no_persist = false;             // eigen-solver: take the launch-per-step tridiagonalisation (retry after a hand-off time-out)
+    // early start of the leading block (k_early.hip): staging + flags (grow-only), and the D array known to hold the sentinel
+    void *early_buf = nullptr; size_t early_bytes = 0; const void *early_clean = nullptr;
     // generic scratch arena (grow-only)
     void *arena = nullptr;
     size_t arena_bytes = 0;

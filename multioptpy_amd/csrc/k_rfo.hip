@@ -9,14 +9,16 @@
 
 namespace mopt {
 
+// (gfb: the vector the identity fallback takes -- the projected gradient itself when gp is Q^T g and Vt holds the eigenvectors of the
+// tridiagonal form, see pipeline.hip; null: gp)
 __global__ void __launch_bounds__(256) k_vtg(int n, const double *__restrict__ Vt, const double *__restrict__ gp,
-                                             const int *__restrict__ einfo, double *__restrict__ gt_all) {
+                                             const int *__restrict__ einfo, double *__restrict__ gt_all, const double *__restrict__ gfb) {
     const int b = blockIdx.y, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int i = blockIdx.x * 4 + wid;
     if (i >= n) return;
     const double *g = gp + (size_t)b * n;
     if (einfo[2 * b + 1] & 1) {           // eigensolver produced non-finite values: identity fallback (rsirfo.py:365-369)
-        if (lane == 0) gt_all[(size_t)b * n + i] = g[i];
+        if (lane == 0) gt_all[(size_t)b * n + i] = gfb ? gfb[(size_t)b * n + i] : g[i];
         return;
     }
     const double *v = Vt + ((size_t)b * n + i) * n;
@@ -50,6 +52,8 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
                                                    const double *__restrict__ Be, const UpdateCoef *__restrict__ coef,
                                                    double *__restrict__ coef_out_, int dbg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    // one latency-bound wave per image, usually running next to the back-transformation (pipeline.hip): highest issue priority on its SIMD
+    __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x, lane = threadIdx.x;
     double *w0 = sm;             // [n] eigenvalues of the projected Hessian (ascending)
     double *g0 = w0 + n;         // [n] v_i . g in that order
@@ -276,25 +280,34 @@ __global__ void __launch_bounds__(1024) k_backtransform(int n, const double *__r
 }  // namespace mopt
 
 
+int mopt_launch_rfo_scalar(mopt_ctx *ctx, hipStream_t st, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
+                           const double *d_W, const int *d_perm, const int *d_einfo, const double *d_gt_all, const double *d_Bg, const double *d_Be,
+                           const mopt::UpdateCoef *d_coef, double *d_coefout) {
+    using namespace mopt;
+    static const int dbg = getenv("MOPT_RFO_DBG") ? 1 : 0;
+    const size_t lds = (size_t)9 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
+    if (lds > 48000) MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+    hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(64), lds, st, n, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout, dbg);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,
                     const double *d_Bg, const double *d_Be, const mopt::UpdateCoef *d_coef, double *d_gt_all,
                     double *d_coefout, double *d_step) {
     using namespace mopt;
     mopt_scope sc(ctx, "rfo", 3);
-    const size_t lds = (size_t)9 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
-    if (lds > 48000) MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-    hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_gp, d_einfo, d_gt_all);
-    hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(64), lds, ctx->stream, n, d_params, d_states, d_W, d_perm, d_einfo,
-                       d_gt_all, d_Bg, d_Be, d_coef, d_coefout, getenv("MOPT_RFO_DBG") ? 1 : 0);
+    hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_gp, d_einfo, d_gt_all, (const double *)nullptr);
+    { const int rc = mopt_launch_rfo_scalar(ctx, ctx->stream, n, batch, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout); if (rc != MOPT_OK) return rc; }
     hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(1024), 0, ctx->stream, n, d_Vt, d_coefout, d_einfo, d_step);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }
 
-int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out) {
+int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out, const double *d_fallback) {
     using namespace mopt;
-    hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_vec, d_einfo, d_out);
+    hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_vec, d_einfo, d_out, d_fallback);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

@@ -1638,7 +1638,7 @@ __global__ void __launch_bounds__(MAXM * 2) k_tri_small(int n, const double *__r
 // max-norm for the iteration.  Same contract as k_tri_small: WT[s .. t) and rows s .. t-1 of Zt (zero outside the block).
 __global__ void __launch_bounds__(64) k_tri_ql32(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
                                                  const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_, int *__restrict__ fail_,
-                                                 const int *__restrict__ dcflag_) {
+                                                 const int *__restrict__ dcflag_, const double *__restrict__ stage_, const int *__restrict__ early_) {
     __shared__ double Zs[32 * 32];
     if (dcflag_ && dcflag_[blockIdx.y]) return;
     const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;
@@ -1647,16 +1647,25 @@ __global__ void __launch_bounds__(64) k_tri_ql32(int n, const double *__restrict
     const int s = i0, t = bend[i0], m = t - s;
     if (m < 2 || m > 32) return;
     const double *D = D_ + (size_t)b * n + s, *E = E_ + (size_t)b * n + s;
-    double d = (lane < m) ? D[lane] : 0.0;
-    double e = (lane < m - 1) ? E[lane] : 0.0;
-    const double nrm = wave_max(fmax(fabs(d), fabs(e)));
-    const double sc = (nrm > 0.0) ? nrm : 1.0;
-    d /= sc; e /= sc;
-    for (int c = 0; c < m; ++c) Zs[c * 32 + (lane & 31)] = ((lane & 31) == c) ? 1.0 : 0.0;
-    __syncthreads();
-    const bool ok = ql_block32(m, d, e, Zs, lane);
-    __syncthreads();
-    if (!ok && lane == 0) atomicAdd(&fail_[b], 1);
+    double d, sc = 1.0;
+    if (early_ && s == 0 && early_[b] == m) {
+        // the leading block was solved by k_tri_early (k_early.hip) while the tridiagonalisation was still running
+        const double *stage = stage_ + (size_t)b * MOPT_EARLY_STAGE;
+        d = (lane < m) ? stage[lane] : 0.0;
+        for (int i = lane; i < 32 * m; i += WAVE) Zs[i] = stage[32 + i];
+        __syncthreads();
+    } else {
+        d = (lane < m) ? D[lane] : 0.0;
+        double e = (lane < m - 1) ? E[lane] : 0.0;
+        const double nrm = wave_max(fmax(fabs(d), fabs(e)));
+        sc = (nrm > 0.0) ? nrm : 1.0;
+        d /= sc; e /= sc;
+        for (int c = 0; c < m; ++c) Zs[c * 32 + (lane & 31)] = ((lane & 31) == c) ? 1.0 : 0.0;
+        __syncthreads();
+        const bool ok = ql_block32(m, d, e, Zs, lane);
+        __syncthreads();
+        if (!ok && lane == 0) atomicAdd(&fail_[b], 1);
+    }
     if (lane < m) WT_[(size_t)b * n + s + lane] = d * sc;
     double *Zt = Zt_ + (size_t)b * n * n;
     for (int c = 0; c < m; ++c) {
@@ -2007,7 +2016,7 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
 
 // ascending sort of WT -> W, perm (same contract as k_jac_finalize); dynamic LDS npow2 * 12 bytes
 __global__ void __launch_bounds__(1024) k_tri_sort(int n, int npow2, const double *__restrict__ WT_, const int *__restrict__ fail_,
-                                                  double *__restrict__ W, int *__restrict__ perm, int *__restrict__ info) {
+                                                  double *__restrict__ W, int *__restrict__ perm, int *__restrict__ info, double *clrD, double *clrE) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *key = sm;
     int *idx = (int *)(sm + npow2);
@@ -2047,6 +2056,8 @@ __global__ void __launch_bounds__(1024) k_tri_sort(int n, int npow2, const doubl
     // Non-finite eigenvalues (a NaN / Inf Hessian, rsirfo.py:365-372: "common for linear molecules and poor initial guesses") are not
     // a solver failure: the consumers replace such an eigen-system by (w = 1, V = I) and continue as steepest descent, as the reference.
     if (threadIdx.x == 0) { const int f = fail_[b]; info[2 * b] = 0; info[2 * b + 1] = bad ? 1 : ((f ? 4 : 0) | (f >= TRI_FAIL_TIMEOUT ? 8 : 0)); }
+    // last reader of D and E in a solve: leave the all-ones sentinel k_tri_early (k_early.hip) expects in front of the next solve
+    if (clrD) for (int i = threadIdx.x; i < n; i += blockDim.x) { ((unsigned long long *)clrD)[(size_t)b * n + i] = ~0ull; ((unsigned long long *)clrE)[(size_t)b * n + i] = ~0ull; }
 }
 
 }  // namespace mopt
@@ -2079,9 +2090,15 @@ int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double
 // d_Z2: batch*(n*n + MOPT_TRI_T_DOUBLES(n)) doubles (scratch copy of the eigenvectors for the cluster orthogonalisation, then the T factors of the blocked back-transformation).  d_bstart, d_bend: batch*n ints; d_cstart: 2*batch*n ints (tight and loose cluster tables); d_ncl: 2*batch ints; d_fail: batch ints.
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info, double *d_Z2) {
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook) {
     using namespace mopt;
     if (n < 3) { ctx->err = "tridiagonal eigen-solver needs n >= 3"; return MOPT_E_ARG; }
+    if (hook) hook->used = false;
+    double *early_stage = nullptr, *clr_D = nullptr, *clr_E = nullptr;      // early start of the leading block (k_early.hip)
+    int *early_flag = nullptr;
+    const int small_max_early = tri_env("MOPT_TRI_SMALL") ? atoi(tri_env("MOPT_TRI_SMALL")) : 64;
+    const bool early_was_clean = (ctx->early_clean == (const void *)d_D);      // the previous solve on these arrays left the sentinel in D, E
+    ctx->early_clean = nullptr;                              // (any route writes D, E; only a solve that ends with the clearing k_tri_sort re-arms it)
     // (set on every call: contexts of several devices live in one process, and the attribute is per device)
     MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_invit, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
     MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
@@ -2212,6 +2229,31 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const size_t xwords = (size_t)8 * n + G;               // p vectors, pivot rows (two buffers each, two tagged words per value), XCC ids
         MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
         int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;
+        // early start of the leading block's eigen-solve on the helper stream, next to the (first) persistent launch (k_early.hip);
+        // D and E carry the sentinel from the previous solve's k_tri_sort, or are filled here
+        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !(tri_env("MOPT_TRI_EARLY") && atoi(tri_env("MOPT_TRI_EARLY")) == 0);
+        if (use_early) {
+            const size_t need = (size_t)batch * (MOPT_EARLY_STAGE * 8 + 8);
+            if (ctx->early_bytes < need) {
+                MOPT_HIP_TRY(ctx, hipDeviceSynchronize());
+                if (ctx->early_buf) MOPT_HIP_TRY(ctx, hipFree(ctx->early_buf));
+                ctx->early_buf = nullptr; ctx->early_bytes = 0;
+                MOPT_HIP_TRY(ctx, hipMalloc(&ctx->early_buf, need));
+                ctx->early_bytes = need;
+            }
+            early_stage = (double *)ctx->early_buf;
+            early_flag = (int *)((char *)ctx->early_buf + (size_t)batch * MOPT_EARLY_STAGE * 8);
+            if (!early_was_clean) {
+                MOPT_HIP_TRY(ctx, hipMemsetAsync(d_D, 0xFF, (size_t)batch * n * 8, ctx->stream));
+                MOPT_HIP_TRY(ctx, hipMemsetAsync(d_E, 0xFF, (size_t)batch * n * 8, ctx->stream));
+            }
+            clr_D = d_D; clr_E = d_E;                         // (k_tri_sort leaves the sentinel behind this solve)
+            MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork4, ctx->stream));
+            MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork4, 0));
+            mopt_scope sce(ctx, "eigh_early", 1, ctx->side);  // (helper stream)
+            const int rc = mopt_launch_tri_early(ctx, ctx->side, n, batch, d_D, d_E, (const void *)d_Vt, (size_t)n * n, early_stage, early_flag);
+            if (rc != MOPT_OK) return rc;
+        }
         for (int b0 = 0; b0 < batch; b0 += per) {
             const int nb_ = (batch - b0 < per) ? batch - b0 : per;
             int per_x = (nb_ + 7) / 8;                          // matrices per XCD
@@ -2348,10 +2390,18 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     const bool bt_mfma = mopt_bt_use_mfma(n);
     const int bt_NB = (n - 2 + 15) / 16;
     double *bt_T = d_Z2 + (size_t)batch * n * n;
+    const bool use_hook = hook && hook->front && hook->scalar && hook->gp && hook->gq && bt_mfma && mopt_apply_qt_supported(n) &&
+                          !(tri_env("MOPT_RFO_OVERLAP") && atoi(tri_env("MOPT_RFO_OVERLAP")) == 0);
     if (bt_mfma) {
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
-        { const int rc = mopt_launch_bt_larft(ctx, ctx->side2, n, batch, d_A, d_TAU, bt_T); if (rc != MOPT_OK) return rc; }
+        { mopt_scope scl(ctx, "larft", 1, ctx->side2); const int rc = mopt_launch_bt_larft(ctx, ctx->side2, n, batch, d_A, d_TAU, bt_T); if (rc != MOPT_OK) return rc; }
+        if (use_hook) {                                      // gq = Q^T gp behind the T factors, see EighRfoHook (pipeline.h)
+            if (hook->ev_gp) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, hook->ev_gp, 0));
+            mopt_scope sca(ctx, "apply_qt", 1, ctx->side2);      // (helper stream)
+            const int rc = mopt_launch_apply_qt(ctx, ctx->side2, n, batch, d_A, bt_T, hook->gp, hook->gq);
+            if (rc != MOPT_OK) return rc;
+        }
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));
     }
     // divide and conquer (k_dc.hip) for matrices with an unreduced block of more than dc_min rows; MOPT_TRI_DC=0 switches it off
@@ -2371,12 +2421,18 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     int small_max = tri_env("MOPT_TRI_SMALL") ? atoi(tri_env("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
     if (small_max > TRI_SMALL) small_max = TRI_SMALL;
     if (small_max < 0) small_max = 0;
+    // (Both chains -- bisection / inverse iteration on the main stream, divide and conquer on its helper stream -- are enqueued on every
+    // call, each kernel skipping the matrices of the other chain.  Skipping the idle D&C chain on the strength of the previous call's
+    // flags was tried and removed: it gained nothing measurable -- the chain is not what the back-transformation waits for -- and one
+    // misprediction sends dense matrices through the sequential cluster walk, seconds per step.)
     if (d_dcflag) {
-        // divide and conquer for the flagged matrices, the whole chain on its own helper stream (its kernels return at once for
-        // the others; k_tri_clusters / k_tri_invit / k_tri_lowdin on the main stream do the same for the flagged ones)
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork5, ctx->stream));
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side3, ctx->ev_fork5, 0));
         hipLaunchKernelGGL(k_dc_flag, dim3(batch), dim3(256), (size_t)n * 4, ctx->side3, n, d_D, d_E, dc_min, d_dcflag);
+    }
+    if (d_dcflag) {
+        // divide and conquer for the flagged matrices, the whole chain on its own helper stream (its kernels return at once for
+        // the others; k_tri_clusters / k_tri_invit / k_tri_lowdin on the main stream do the same for the flagged ones)
         mopt_scope scd(ctx, "eigh_dc", 4 + 5 * mopt::dc_levels(n), ctx->side3);      // (helper stream: overlaps the main-stream families)
         const int rc = mopt_launch_dc(ctx, ctx->side3, n, batch, d_D, d_E, d_dcflag, d_WT, d_Vt, d_Z2, d_bstart, d_bend, d_fail,
                                       (char *)ctx->arena + 256);
@@ -2392,13 +2448,15 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             // passes of the larger blocks (k_tri_clusters does not read the eigenvalues of small blocks); joined before V = Q Z.
             MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork4, ctx->stream));
             MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork4, 0));
+            mopt_scope scs(ctx, "eigh_small", 2, ctx->side);      // (helper stream)
             // (two instantiations: one wave for blocks of 2 .. 32 rows, two waves for 33 .. 64 rows -- the Hessians of a long NEB
             // run grow blocks of 33-48 rows around a ~20-fold eigenvalue, which cost the inverse iteration 2-3 ms per cluster)
             MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_small<64, 33>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
             // blocks of 2 .. 32 rows: implicit QL (MOPT_TRI_QL=0: the one-sided Jacobi of round 1)
             const bool use_ql = !(tri_env("MOPT_TRI_QL") && atoi(tri_env("MOPT_TRI_QL")) == 0);
             if (small_max > 0 && use_ql)
-                hipLaunchKernelGGL(k_tri_ql32, dim3(n, batch), dim3(64), 0, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
+                hipLaunchKernelGGL(k_tri_ql32, dim3(n, batch), dim3(64), 0, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag,
+                                   (const double *)early_stage, (const int *)early_flag);
             else if (small_max > 0)
                 hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
             if (small_max > 32)
@@ -2426,22 +2484,48 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                                d_Vt, d_Z2, small_max, (const int *)d_perm, (const int *)d_info);
         }
     }
+    if (tri_env("MOPT_TRI_BLOCKDBG")) {                      // developer aid: unreduced blocks of a few matrices of the batch
+        std::vector<int> hs((size_t)batch * n), he((size_t)batch * n);
+        hipDeviceSynchronize();
+        hipMemcpy(hs.data(), d_bstart, hs.size() * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(he.data(), d_bend, he.size() * 4, hipMemcpyDeviceToHost);
+        for (int b = 0; b < batch; b += (batch > 4 ? batch / 4 : 1)) {
+            fprintf(stderr, "[blocks] matrix %d:", b);
+            for (int i = 0; i < n;) { const int t = he[(size_t)b * n + i]; if (t <= i) break; fprintf(stderr, " %d", t - i); i = t; }
+            fprintf(stderr, "\n");
+        }
+    }
     if (small_max > 0) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join4, 0));      // the small blocks' eigenpairs (side stream)
     if (d_dcflag) {                                          // the divide-and-conquer chain (third helper stream)
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join5, ctx->side3));
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
     }
     if (bt_mfma) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the T factors (side stream)
-    { const int rc = mopt_launch_backtrans(ctx, n, batch, d_A, d_TAU, bt_T, d_Vt, d_bend, bt_mfma); if (rc != MOPT_OK) return rc; }
     if (tri_env("MOPT_TRI_INJECT_FAIL")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 1, sizeof(int), ctx->stream));   // test hook: matrix 0 fails
     if (tri_env("MOPT_TRI_INJECT_TIMEOUT") && !ctx->tri_no_persist)       // test hook: matrix 0 reports a hand-off time-out on the persistent route
         MOPT_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)d_fail, TRI_FAIL_TIMEOUT, 1, ctx->stream));
-    {
+    auto sort_eigenvalues = [&]() {                          // ascending order (rank sort) + the failure flags: independent of the eigenvectors
         mopt_scope sc(ctx, "eigh_final", 1);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
-        hipLaunchKernelGGL(k_tri_sort, dim3(batch), dim3(n <= 256 ? 256 : n <= 512 ? 512 : 1024), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_WT, d_fail, d_W, d_perm, d_info);
+        hipLaunchKernelGGL(k_tri_sort, dim3(batch), dim3(n <= 256 ? 256 : n <= 512 ? 512 : 1024), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_WT, d_fail, d_W, d_perm, d_info, clr_D, clr_E);
+    };
+    if (use_hook) {
+        // the caller's scalar stage next to V = Q Z: its inputs are the eigenvalues and Z^T (Q^T g)
+        sort_eigenvalues();
+        { const int rc = hook->front(ctx, hook->user, d_Vt, hook->gq); if (rc != MOPT_OK) return rc; }
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork6, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork6, 0));
+        { const int rc = hook->scalar(ctx, hook->user, ctx->side); if (rc != MOPT_OK) return rc; }
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join6, ctx->side));
+        { const int rc = mopt_launch_backtrans(ctx, n, batch, d_A, d_TAU, bt_T, d_Vt, d_bend, bt_mfma); if (rc != MOPT_OK) return rc; }
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join6, 0));
+        hook->used = true;
+    } else {
+        { const int rc = mopt_launch_backtrans(ctx, n, batch, d_A, d_TAU, bt_T, d_Vt, d_bend, bt_mfma); if (rc != MOPT_OK) return rc; }
+        sort_eigenvalues();
     }
     MOPT_HIP_TRY(ctx, hipGetLastError());
+    if (clr_D) ctx->early_clean = (const void *)d_D;
     return MOPT_OK;
 }

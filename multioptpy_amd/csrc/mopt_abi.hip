@@ -4,6 +4,7 @@
 
 #include "common.hpp"
 #include "logic.h"
+#include <algorithm>
 #include "pipeline.h"
 
 using namespace mopt;
@@ -34,7 +35,11 @@ extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
         hipEventCreateWithFlags(&c->ev_join4, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork5, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join5, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join5, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork6, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join6, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev_fork6) hipEventDestroy(c->ev_fork6);
+        if (c->ev_join5) hipEventDestroy(c->ev_join5);
         if (c->ev_fork5) hipEventDestroy(c->ev_fork5);
         if (c->side3) hipStreamDestroy(c->side3);
         if (c->ev_join4) hipEventDestroy(c->ev_join4);
@@ -71,6 +76,8 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipEventDestroy(ctx->ev_fork4); hipEventDestroy(ctx->ev_join4);
     hipStreamSynchronize(ctx->side3);
     hipEventDestroy(ctx->ev_fork5); hipEventDestroy(ctx->ev_join5);
+    hipEventDestroy(ctx->ev_fork6); hipEventDestroy(ctx->ev_join6);
+    if (ctx->early_buf) hipFree(ctx->early_buf);
     hipStreamDestroy(ctx->side3);
     hipStreamDestroy(ctx->side2);
     hipStreamDestroy(ctx->side);
@@ -120,6 +127,32 @@ extern "C" int mopt_ctx_timing(mopt_ctx *ctx, int enable) {
 extern "C" int mopt_ctx_timing_read(mopt_ctx *ctx, const char *family, double *ms, int64_t *launches) {
     if (!ctx || !family) return MOPT_E_ARG;
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (std::string(family) == "timeline") {
+        // developer aid (MOPT timing on): every timed scope of the last ~2 steps in start order -- start and length in us relative to
+        // the first of them, and the idle time since the end of the previous scope on the list -- to stderr
+        struct Rec { std::string name; float start, len; };
+        std::vector<Rec> recs;
+        hipEvent_t base = nullptr;
+        for (auto &kv : ctx->timers) if (!kv.second.ev.empty()) { base = kv.second.ev.front().first; break; }
+        if (base) {
+            for (auto &kv : ctx->timers)
+                for (auto &e : kv.second.ev) {
+                    float a = 0.f, l = 0.f;
+                    if (hipEventElapsedTime(&a, base, e.first) == hipSuccess && hipEventElapsedTime(&l, e.first, e.second) == hipSuccess) recs.push_back({kv.first, a * 1e3f, l * 1e3f});
+                }
+            std::sort(recs.begin(), recs.end(), [](const Rec &x, const Rec &y) { return x.start < y.start; });
+            const char *all = getenv("MOPT_TIMELINE_ALL");
+            const size_t from = (all || recs.size() <= 40) ? 0 : recs.size() - 40;
+            float prev_end = recs.empty() ? 0.f : recs[from].start;
+            for (size_t i = from; i < recs.size(); ++i) {
+                fprintf(stderr, "[timeline] %9.1f us  %-16s %8.1f us   (gap %6.1f)\n", recs[i].start - recs[from].start, recs[i].name.c_str(), recs[i].len, recs[i].start - prev_end);
+                if (recs[i].start + recs[i].len > prev_end) prev_end = recs[i].start + recs[i].len;
+            }
+        }
+        if (ms) *ms = 0.0;
+        if (launches) *launches = 0;
+        return MOPT_OK;
+    }
     auto it = ctx->timers.find(family);
     double tot = 0.0; int64_t nl = 0;
     if (it != ctx->timers.end()) {

@@ -71,21 +71,45 @@ int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
                      int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps, bool warm);
 int mopt_launch_dgemm(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_B, const double *d_addscale, double *d_C);
+// Optional hook of the reduction route: the caller's scalar stage runs NEXT TO the back-transformation V = Q Z.  With g~ = V^T g =
+// Z^T (Q^T g) the stage needs only the eigenvalues and the eigenvectors Z of the tridiagonal form (k_applyq.hip):
+//   helper stream 2:  T factors -> gq = Q^T gp            (gp must be complete when ev_gp has fired)
+//   main stream:      ... eigenpairs of T -> sort -> front(Z, gq) -> [fork] back-transformation -> [join]
+//   helper stream 1:                                               scalar(stream)
+// `used` tells the caller whether the solver took the hook (it does not for sizes without the blocked back-transformation).
+struct EighRfoHook {
+    const double *gp = nullptr; double *gq = nullptr; hipEvent_t ev_gp = nullptr;
+    void *user = nullptr;
+    int (*front)(mopt_ctx *, void *user, const double *d_Zt, const double *d_gq) = nullptr;
+    int (*scalar)(mopt_ctx *, void *user, hipStream_t st) = nullptr;
+    bool used = false;
+};
+// early start of the leading block's eigen-solve next to the tridiagonalisation (k_early.hip)
+#define MOPT_EARLY_STAGE (32 + 32 * 32)   /* doubles per matrix: eigenvalues, eigenvector table (column-major, stride 32) */
+int mopt_launch_tri_early(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_D, const double *d_E, const void *d_xch, size_t xch_stride_u64,
+                          double *d_stage, int *d_early);
+bool mopt_apply_qt_supported(int n);
+int mopt_launch_apply_qt(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_A, const double *d_T, const double *d_in, double *d_out);
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info, double *d_Z2);
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook = nullptr);
 // algorithm switch: 0 = block Jacobi (k_eigh.hip), 1 = tridiagonal reduction route (k_tridiag.hip); env MOPT_EIGH_ALGO overrides
-int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, bool preserve_A = true);
+int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, bool preserve_A = true, EighRfoHook *hook = nullptr);
 int mopt_eigh_algo(int n);   // 1 = reduction route (k_tridiag.hip), 0 = one-sided Jacobi (k_eigh.hip)
 int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const int *d_perm, double *d_V);
+// the three kernels of mopt_launch_rfo one by one (pipeline.hip overlaps the middle one with the back-transformation)
+int mopt_launch_rfo_scalar(mopt_ctx *ctx, hipStream_t st, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
+                           const double *d_W, const int *d_perm, const int *d_einfo, const double *d_gt_all, const double *d_Bg, const double *d_Be,
+                           const mopt::UpdateCoef *d_coef, double *d_coefout);
+int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out,
+                    const double *d_fallback = nullptr);
+int mopt_launch_backtransform(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_coef, const int *d_einfo, double *d_out);
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,
                     const double *d_Bg, const double *d_Be, const mopt::UpdateCoef *d_coef, double *d_gt_all,
                     double *d_coefout, double *d_step);
 int mopt_launch_neb_force_var(mopt_ctx *ctx, int variant, int I, int N, int first, int count, const double *d_X, const double *d_E,
                               const double *d_G, int ci_active, double *d_F);
-int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out);
-int mopt_launch_backtransform(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_coef, const int *d_einfo, double *d_out);
 int mopt_launch_norm_inf(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma);   // sigma = 1.0625 * ||A||_inf
 int mopt_launch_bneb_force(mopt_ctx *ctx, int I, int N, int first, int count, const double *d_X, const double *d_E,
                            const double *d_G, int ci_active, double *d_F, double *d_tau);

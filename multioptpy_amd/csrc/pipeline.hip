@@ -73,8 +73,28 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
         rc = mopt_launch_project_hess(ctx, n, batch, d_Hsym, wk.Bias, wk.x, wk.Q, wk.W6, wk.A, /*basis_ready=*/true);
         if (rc != MOPT_OK) return rc;
     }
-    rc = mopt_eigh_auto(ctx, wk, n, batch, warm_eigh, /*preserve_A=*/false);
+    // The scalar stage of the step (k_rfo_scalar: one wave per image) runs next to the back-transformation when the solver takes the
+    // hook: g~ = V^T g = Z^T (Q^T g) needs the tridiagonal form's eigenvectors only (k_applyq.hip, EighRfoHook in pipeline.h).
+    struct HookUser { RsirfoWork *wk; int n, batch; const mopt::UpdateCoef *coef; } hu = {&wk, n, batch, coef};
+    EighRfoHook hook;
+    hook.gp = wk.gp; hook.gq = wk.Hy; hook.ev_gp = ctx->ev_join2; hook.user = &hu;
+    hook.front = [](mopt_ctx *c, void *u, const double *d_Zt, const double *d_gq) -> int {
+        HookUser *h = (HookUser *)u;
+        mopt_scope sc(c, "rfo", 1);
+        return mopt_launch_vtg(c, h->n, h->batch, d_Zt, d_gq, h->wk->einfo, h->wk->gt_all, h->wk->gp);
+    };
+    hook.scalar = [](mopt_ctx *c, void *u, hipStream_t st) -> int {
+        HookUser *h = (HookUser *)u;
+        RsirfoWork &w = *h->wk;
+        mopt_scope sc(c, "rfo_scalar", 1, st);               // (helper stream: overlaps eigh_backtrans)
+        return mopt_launch_rfo_scalar(c, st, h->n, h->batch, w.params, w.states, w.eigw, w.perm, w.einfo, w.gt_all, w.bg, w.be, h->coef, w.coefout);
+    };
+    rc = mopt_eigh_auto(ctx, wk, n, batch, warm_eigh, /*preserve_A=*/false, &hook);
     if (rc != MOPT_OK) return rc;
+    if (hook.used) {
+        mopt_scope sc(ctx, "rfo", 1);
+        return mopt_launch_backtransform(ctx, n, batch, wk.Vt, wk.coefout, wk.einfo, wk.step);
+    }
     MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));       // the projected gradient (side stream)
     rc = mopt_launch_rfo(ctx, n, batch, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, wk.gp, wk.bg, wk.be, coef,
                          wk.gt_all, wk.coefout, wk.step);
@@ -83,7 +103,8 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
 
 // eigh(wk.A) -> wk.eigw (ascending through wk.perm), wk.Vt (vector-major), wk.einfo; wk.A is preserved unless the caller
 // says it is not needed any more (the RS-I-RFO pipeline: the reflectors then overwrite it in place, one n^2 copy less)
-int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, bool preserve_A) {
+int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, bool preserve_A, EighRfoHook *hook) {
+    if (hook) hook->used = false;
     if (mopt_eigh_algo(n) == 1) {
         // reduction route: the reflectors overwrite the input, eigenvectors land in Vt
         double *work = wk.A;
@@ -92,7 +113,7 @@ int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, b
             work = wk.Gt;
         }
         return mopt_launch_eigh_tridiag(ctx, n, batch, work, wk.Vt, wk.tri.D, wk.tri.E, wk.tri.TAU, wk.tri.WT, wk.tri.onenrm, wk.tri.bstart,
-                                        wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo, wk.tri.Z2);
+                                        wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo, wk.tri.Z2, hook);
     }
     return mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm);
 }
