@@ -180,7 +180,8 @@ __global__ void __launch_bounds__(256) k_tri_larft(int n, int NB, const double *
 
 template <int NT, int WPW>
 __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, const double *__restrict__ A_, const double *__restrict__ T_,
-                                                            double *__restrict__ Zt_, const int *__restrict__ bend_) {
+                                                            const double *Zt_, const int *__restrict__ bend_, double *Vout_) {
+    // (Vout_ may be Zt_ itself: a wave reads its 16 vectors completely before it writes them)
     constexpr int LEN = 16 * NT;                                           // padded vector length
     constexpr int LDV = LEN + ((2 - LEN % 32 + 32) % 32);                   // = 2 mod 32: the 16 x 2 operand reads of step 1 hit 32 different bank pairs
     constexpr int NTHR = 64 * WPW, NTL = 256 / NTHR;      // T entries per thread
@@ -192,7 +193,8 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
     const int li = lane & 15, lh = lane >> 4;
     const double *A = A_ + (size_t)b * n * n;
     const double *Tg = T_ + (size_t)b * NB * 256;
-    double *Zt = Zt_ + (size_t)b * n * n;
+    const double *Zt = Zt_ + (size_t)b * n * n;
+    double *Vout = Vout_ + (size_t)b * n * n;
     const int j0 = blockIdx.x * (16 * WPW) + wid * 16;                              // first eigenvector of this wave
     double z[4 * NT];
 #pragma unroll
@@ -305,7 +307,7 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
         }
     });
 #pragma unroll
-    for (int r = 0; r < 4 * NT; ++r) { const int k = 4 * r + lh; if (j0 + li < n && k < n) Zt[(size_t)(j0 + li) * n + k] = z[r]; }
+    for (int r = 0; r < 4 * NT; ++r) { const int k = 4 * r + lh; if (j0 + li < n && k < n) Vout[(size_t)(j0 + li) * n + k] = z[r]; }
 }
 
 }  // namespace mopt
@@ -326,7 +328,11 @@ int mopt_launch_bt_larft(mopt_ctx *ctx, hipStream_t st, int n, int batch, const 
     return MOPT_OK;
 }
 
-int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_TAU, const double *d_T, double *d_Vt, const int *d_bend, bool mfma) {
+// d_Vout: where V goes (null: in place; another buffer only with the blocked form)
+int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_TAU, const double *d_T, double *d_Vt, const int *d_bend, bool mfma,
+                          double *d_Vout) {
+    if (!d_Vout) d_Vout = d_Vt;
+    if (!mfma && d_Vout != d_Vt) { ctx->err = "back-transformation: a separate output needs the blocked form"; return MOPT_E_ARG; }
     using namespace mopt;
     const int nt16 = (n + 15) / 16;
     mopt_scope sc(ctx, "eigh_backtrans", 1);
@@ -337,7 +343,7 @@ int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, co
         // thread, 320 / 608 workgroups): 0.58 / 1.11 ms against 0.148 ms
 #define BTW(NT_, W_) do { constexpr int LEN_ = 16 * NT_, LDV_ = LEN_ + ((2 - LEN_ % 32 + 32) % 32); const size_t lds = ((size_t)16 * LDV_ + 16 * 17) * 8; \
         MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_backtrans_mfma<NT_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024)); \
-        hipLaunchKernelGGL((k_tri_backtrans_mfma<NT_, W_>), dim3((n + 16 * W_ - 1) / (16 * W_), batch), dim3(64 * W_), lds, ctx->stream, n, NB, d_A, d_T, d_Vt, d_bend); } while (0)
+        hipLaunchKernelGGL((k_tri_backtrans_mfma<NT_, W_>), dim3((n + 16 * W_ - 1) / (16 * W_), batch), dim3(64 * W_), lds, ctx->stream, n, NB, d_A, d_T, (const double *)d_Vt, d_bend, d_Vout); } while (0)
 #define BTM(NT_) BTW(NT_, 4)
         if (nt16 <= 4) BTM(4); else if (nt16 <= 8) BTM(8); else if (nt16 <= 12) BTM(12); else if (nt16 <= 16) BTM(16); else if (nt16 <= 19) BTM(19);
         else if (nt16 <= 24) BTM(24); else if (nt16 <= 32) BTM(32); else BTM(38);

@@ -305,9 +305,10 @@ int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d
     return MOPT_OK;
 }
 
-int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out, const double *d_fallback) {
+int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out, const double *d_fallback,
+                    hipStream_t st) {
     using namespace mopt;
-    hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_vec, d_einfo, d_out, d_fallback);
+    hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, st ? st : ctx->stream, n, d_Vt, d_vec, d_einfo, d_out, d_fallback);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

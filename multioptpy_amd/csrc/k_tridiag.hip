@@ -1366,6 +1366,27 @@ __device__ __forceinline__ int sturm_count(const double *d, const double *e2, in
     return cnt;
 }
 
+// Device-side join with the divide-and-conquer chain.  The chain is enqueued on every call and takes ~100 us on its helper stream even
+// when no matrix is flagged (~25 launches that return at once); a stream-level join made the back-transformation wait for that.
+// k_dc_signal ends the chain and publishes the call's epoch; k_dc_wait (main stream, one wave) returns at once when no matrix of the
+// batch is flagged and otherwise polls for the epoch (kernel boundaries on both sides order the chain's results before the readers).
+__global__ void k_dc_signal(unsigned *word, unsigned epoch) {
+    if (threadIdx.x == 0) __hip_atomic_store(word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ void __launch_bounds__(64) k_dc_wait(int batch, const int *__restrict__ dcflag, const unsigned *word, unsigned epoch, int *__restrict__ fail_) {
+    int any = 0;
+    for (int i = threadIdx.x; i < batch; i += WAVE) any |= dcflag[i];
+    if (__ballot(any != 0) == 0ull) return;
+    unsigned spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+        if (++spins > 20000000u) {                           // (seconds: the chain never finished -- its matrices are reported as failed)
+            for (int i = threadIdx.x; i < batch; i += WAVE) if (dcflag[i]) atomicAdd(&fail_[i], 1);
+            return;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // Per-matrix switch of the divide-and-conquer solver: 1 when the split tridiagonal (same criterion as k_tri_bisect) keeps an
 // unreduced block of more than dc_min rows.  grid B, block 256, dynamic LDS n ints.  Runs on the helper stream of the D&C chain
 // right behind the tridiagonalisation, so that the chain does not wait for k_tri_bisect.
@@ -2078,7 +2099,8 @@ static const char *tri_env(const char *name) {
 // back-transformation kernels: k_backtrans.hip
 bool mopt_bt_use_mfma(int n);
 int mopt_launch_bt_larft(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_A, const double *d_TAU, double *d_T);
-int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_TAU, const double *d_T, double *d_Vt, const int *d_bend, bool mfma);
+int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, const double *d_TAU, const double *d_T, double *d_Vt, const int *d_bend, bool mfma,
+                          double *d_Vout = nullptr);
 int mopt_tri_tail_max();
 int mopt_launch_tri_tail(mopt_ctx *ctx, hipStream_t st, int n, int K, int batch, double *d_A, double *d_D, double *d_E, double *d_TAU,
                          long long *d_prof = nullptr);
@@ -2094,6 +2116,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     using namespace mopt;
     if (n < 3) { ctx->err = "tridiagonal eigen-solver needs n >= 3"; return MOPT_E_ARG; }
     if (hook) hook->used = false;
+    MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));      // the previous solve's D&C chain (it is not joined at the end of a solve any more)
     double *early_stage = nullptr, *clr_D = nullptr, *clr_E = nullptr;      // early start of the leading block (k_early.hip)
     int *early_flag = nullptr;
     const int small_max_early = tri_env("MOPT_TRI_SMALL") ? atoi(tri_env("MOPT_TRI_SMALL")) : 64;
@@ -2390,19 +2413,20 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     const bool bt_mfma = mopt_bt_use_mfma(n);
     const int bt_NB = (n - 2 + 15) / 16;
     double *bt_T = d_Z2 + (size_t)batch * n * n;
-    const bool use_hook = hook && hook->front && hook->scalar && hook->gp && hook->gq && bt_mfma && mopt_apply_qt_supported(n) &&
+    const bool use_hook = hook && hook->front && hook->scalar && hook->gp && hook->gq && hook->vout && bt_mfma && mopt_apply_qt_supported(n) &&
                           !(tri_env("MOPT_RFO_OVERLAP") && atoi(tri_env("MOPT_RFO_OVERLAP")) == 0);
     if (bt_mfma) {
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
         { mopt_scope scl(ctx, "larft", 1, ctx->side2); const int rc = mopt_launch_bt_larft(ctx, ctx->side2, n, batch, d_A, d_TAU, bt_T); if (rc != MOPT_OK) return rc; }
+        if (use_hook) MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));      // the T factors alone: all the back-transformation waits for
         if (use_hook) {                                      // gq = Q^T gp behind the T factors, see EighRfoHook (pipeline.h)
             if (hook->ev_gp) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side2, hook->ev_gp, 0));
             mopt_scope sca(ctx, "apply_qt", 1, ctx->side2);      // (helper stream)
             const int rc = mopt_launch_apply_qt(ctx, ctx->side2, n, batch, d_A, bt_T, hook->gp, hook->gq);
             if (rc != MOPT_OK) return rc;
-        }
-        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));
+            MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork6, ctx->side2));      // gq ready: the scalar stage's stream waits for it, not the main stream
+        } else MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));
     }
     // divide and conquer (k_dc.hip) for matrices with an unreduced block of more than dc_min rows; MOPT_TRI_DC=0 switches it off
     const int dc_min = (tri_env("MOPT_TRI_DC") && atoi(tri_env("MOPT_TRI_DC")) == 0) ? 0 : (tri_env("MOPT_TRI_DCMIN") ? atoi(tri_env("MOPT_TRI_DCMIN")) : TRI_SMALL);
@@ -2414,6 +2438,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             if (ctx->arena) MOPT_HIP_TRY(ctx, hipFree(ctx->arena));
             ctx->arena = nullptr; ctx->arena_bytes = 0;
             MOPT_HIP_TRY(ctx, hipMalloc(&ctx->arena, need));
+            MOPT_HIP_TRY(ctx, hipMemset(ctx->arena, 0, 256));
             ctx->arena_bytes = need;
         }
         d_dcflag = (int *)((char *)ctx->arena + 256 + mopt_dc_scratch_bytes(n, batch));
@@ -2497,8 +2522,14 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     }
     if (small_max > 0) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join4, 0));      // the small blocks' eigenpairs (side stream)
     if (d_dcflag) {                                          // the divide-and-conquer chain (third helper stream)
-        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join5, ctx->side3));
-        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
+        static std::map<const mopt_ctx *, unsigned> epochs;      // (one counter per context; the launcher of a context is not re-entered concurrently)
+        unsigned epoch;
+        { static std::mutex mu; std::lock_guard<std::mutex> lk(mu); epoch = ++epochs[ctx]; }
+        unsigned *word = (unsigned *)ctx->arena;                 // (head of the arena: zeroed when it is allocated)
+        hipLaunchKernelGGL(k_dc_signal, dim3(1), dim3(64), 0, ctx->side3, word, epoch);
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join5, ctx->side3));      // (waited for at the start of the next solve: the chain reads this solve's buffers)
+        if (tri_env("MOPT_TRI_DCJOIN") && atoi(tri_env("MOPT_TRI_DCJOIN")) == 1) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
+        else hipLaunchKernelGGL(k_dc_wait, dim3(1), dim3(64), 0, ctx->stream, batch, (const int *)d_dcflag, (const unsigned *)word, epoch, d_fail);
     }
     if (bt_mfma) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the T factors (side stream)
     if (tri_env("MOPT_TRI_INJECT_FAIL")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 1, sizeof(int), ctx->stream));   // test hook: matrix 0 fails
@@ -2512,13 +2543,15 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     };
     if (use_hook) {
         // the caller's scalar stage next to V = Q Z: its inputs are the eigenvalues and Z^T (Q^T g)
+        // main stream: sort -> V = Q Z into hook->vout (Z stays intact in d_Vt);  helper stream: [gq ready] -> front(Z, gq) -> scalar
         sort_eigenvalues();
-        { const int rc = hook->front(ctx, hook->user, d_Vt, hook->gq); if (rc != MOPT_OK) return rc; }
-        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork6, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork4, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork4, 0));
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork6, 0));
+        { const int rc = hook->front(ctx, hook->user, ctx->side, d_Vt, hook->gq); if (rc != MOPT_OK) return rc; }
         { const int rc = hook->scalar(ctx, hook->user, ctx->side); if (rc != MOPT_OK) return rc; }
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join6, ctx->side));
-        { const int rc = mopt_launch_backtrans(ctx, n, batch, d_A, d_TAU, bt_T, d_Vt, d_bend, bt_mfma); if (rc != MOPT_OK) return rc; }
+        { const int rc = mopt_launch_backtrans(ctx, n, batch, d_A, d_TAU, bt_T, d_Vt, d_bend, bt_mfma, hook->vout); if (rc != MOPT_OK) return rc; }
         MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join6, 0));
         hook->used = true;
     } else {

@@ -74,13 +74,15 @@ int mopt_launch_dgemm(mopt_ctx *ctx, int n, int batch, const double *d_A, const 
 // Optional hook of the reduction route: the caller's scalar stage runs NEXT TO the back-transformation V = Q Z.  With g~ = V^T g =
 // Z^T (Q^T g) the stage needs only the eigenvalues and the eigenvectors Z of the tridiagonal form (k_applyq.hip):
 //   helper stream 2:  T factors -> gq = Q^T gp            (gp must be complete when ev_gp has fired)
-//   main stream:      ... eigenpairs of T -> sort -> front(Z, gq) -> [fork] back-transformation -> [join]
-//   helper stream 1:                                               scalar(stream)
-// `used` tells the caller whether the solver took the hook (it does not for sizes without the blocked back-transformation).
+//   main stream:      ... eigenpairs of T -> sort -> V = Q Z written to `vout` (Z stays in d_Vt) -> [join]
+//   helper stream 1:                          [gq ready] -> front(stream, Z, gq) -> scalar(stream)
+// `used` tells the caller whether the solver took the hook (it does not for sizes without the blocked back-transformation); the
+// eigenvectors are then in `vout`, not in d_Vt.
 struct EighRfoHook {
     const double *gp = nullptr; double *gq = nullptr; hipEvent_t ev_gp = nullptr;
+    double *vout = nullptr;
     void *user = nullptr;
-    int (*front)(mopt_ctx *, void *user, const double *d_Zt, const double *d_gq) = nullptr;
+    int (*front)(mopt_ctx *, void *user, hipStream_t st, const double *d_Zt, const double *d_gq) = nullptr;
     int (*scalar)(mopt_ctx *, void *user, hipStream_t st) = nullptr;
     bool used = false;
 };
@@ -102,7 +104,7 @@ int mopt_launch_rfo_scalar(mopt_ctx *ctx, hipStream_t st, int n, int batch, cons
                            const double *d_W, const int *d_perm, const int *d_einfo, const double *d_gt_all, const double *d_Bg, const double *d_Be,
                            const mopt::UpdateCoef *d_coef, double *d_coefout);
 int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out,
-                    const double *d_fallback = nullptr);
+                    const double *d_fallback = nullptr, hipStream_t st = nullptr);
 int mopt_launch_backtransform(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_coef, const int *d_einfo, double *d_out);
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,

@@ -78,10 +78,11 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     struct HookUser { RsirfoWork *wk; int n, batch; const mopt::UpdateCoef *coef; } hu = {&wk, n, batch, coef};
     EighRfoHook hook;
     hook.gp = wk.gp; hook.gq = wk.Hy; hook.ev_gp = ctx->ev_join2; hook.user = &hu;
-    hook.front = [](mopt_ctx *c, void *u, const double *d_Zt, const double *d_gq) -> int {
+    hook.vout = wk.Gt;                                       // (free on the reduction route: the eigenvectors V land there, Z stays in wk.Vt)
+    hook.front = [](mopt_ctx *c, void *u, hipStream_t st, const double *d_Zt, const double *d_gq) -> int {
         HookUser *h = (HookUser *)u;
-        mopt_scope sc(c, "rfo", 1);
-        return mopt_launch_vtg(c, h->n, h->batch, d_Zt, d_gq, h->wk->einfo, h->wk->gt_all, h->wk->gp);
+        mopt_scope sc(c, "rfo_scalar", 1, st);
+        return mopt_launch_vtg(c, h->n, h->batch, d_Zt, d_gq, h->wk->einfo, h->wk->gt_all, h->wk->gp, st);
     };
     hook.scalar = [](mopt_ctx *c, void *u, hipStream_t st) -> int {
         HookUser *h = (HookUser *)u;
@@ -93,7 +94,7 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     if (rc != MOPT_OK) return rc;
     if (hook.used) {
         mopt_scope sc(ctx, "rfo", 1);
-        return mopt_launch_backtransform(ctx, n, batch, wk.Vt, wk.coefout, wk.einfo, wk.step);
+        return mopt_launch_backtransform(ctx, n, batch, hook.vout, wk.coefout, wk.einfo, wk.step);
     }
     MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));       // the projected gradient (side stream)
     rc = mopt_launch_rfo(ctx, n, batch, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, wk.gp, wk.bg, wk.be, coef,
