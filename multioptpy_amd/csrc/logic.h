@@ -396,19 +396,26 @@ MOPT_HD double solve_secular(const R &red, const double *w, const double *gt, in
     return (a + b) / 2.0;
 }
 
-// solve_rfo (rsirfo.py:1688-1715): writes step[0..m), returns ||step||^2 via *norm2; returns lambda_aug
+// step of solve_rfo for a given lambda_aug and its squared norm in one pass (every index is visited by exactly one lane, which squares
+// what it just wrote)
 template <class R>
-MOPT_HD double solve_rfo(const R &red, const double *w, const double *gt, int m, double alpha, double *step,
-                         double *norm2, int *iters, double *cg2 = nullptr, double *cw = nullptr) {
-    double lam = solve_secular(red, w, gt, m, alpha, iters, cg2, cw);
-    // step and its squared norm in one pass (every index is visited by exactly one lane, which squares what it just wrote)
-    *norm2 = red.sum(m, [=](int i) {
+MOPT_HD double form_rfo_step(const R &red, const double *w, const double *gt, int m, double alpha, double lam, double *step) {
+    const double n2 = red.sum(m, [=](int i) {
         double den = safe_den(w[i] / alpha - lam, 1e-20);
         double v = -(gt[i] / alpha) / den;
         step[i] = v;
         return v * v;
     });
     red.sync();
+    return n2;
+}
+
+// solve_rfo (rsirfo.py:1688-1715): writes step[0..m), returns ||step||^2 via *norm2; returns lambda_aug
+template <class R>
+MOPT_HD double solve_rfo(const R &red, const double *w, const double *gt, int m, double alpha, double *step,
+                         double *norm2, int *iters, double *cg2 = nullptr, double *cw = nullptr) {
+    double lam = solve_secular(red, w, gt, m, alpha, iters, cg2, cw);
+    *norm2 = form_rfo_step(red, w, gt, m, alpha, lam, step);
     return lam;
 }
 
@@ -509,7 +516,15 @@ MOPT_HD RsResult rs_step(const R &red, const mopt_rsirfo_params &p, double trust
     bool broke = false;
     for (int mu = 0; mu < max_mc; ++mu) {
         double q;
-        double lam = solve_rfo(red, w, gt, m, alpha, step, &q, nullptr, cg2, cw);
+        double lam;
+        if (mu == 0 && alpha == p.alpha0) {
+            // the first micro cycle repeats the very first solve (same alpha, same inputs: the reference computes the same numbers
+            // twice, rsirfo.py:945 and 1085): its lambda is kept, only the step -- overwritten by the two bracket solves -- is formed again
+            lam = rr.lambda_aug0;
+            q = form_rfo_step(red, w, gt, m, alpha, lam, step);
+        } else {
+            lam = solve_rfo(red, w, gt, m, alpha, step, &q, nullptr, cg2, cw);
+        }
         double nrm = sqrt(q);
         double diff = fabs(nrm - R_);
         if (diff < best_diff) {
