@@ -2096,6 +2096,16 @@ static const char *tri_env(const char *name) {
     cache.emplace(name, v);
     return v;
 }
+// Two kernels of this solver wait for kernels on OTHER streams of the context (k_tri_early for the tridiagonalisation it runs next to,
+// k_dc_wait for the divide-and-conquer chain).  A tool that lets only one kernel run at a time (rocprofv3 counter collection,
+// AMD_SERIALIZE_KERNEL) would turn those waits into time-outs: they are switched off there (MOPT_SERIALIZED=1 does the same by hand).
+static bool serialized_dispatch() {
+    static const bool v = [] {
+        const char *a = ::getenv("ROCPROF_COUNTER_COLLECTION"), *b = ::getenv("ROCPROF_COUNTERS"), *c = ::getenv("AMD_SERIALIZE_KERNEL"), *d = ::getenv("MOPT_SERIALIZED");
+        return (a && atoi(a) != 0) || (b && b[0]) || (c && atoi(c) != 0) || (d && atoi(d) != 0);
+    }();
+    return v;
+}
 // back-transformation kernels: k_backtrans.hip
 bool mopt_bt_use_mfma(int n);
 int mopt_launch_bt_larft(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_A, const double *d_TAU, double *d_T);
@@ -2254,7 +2264,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;
         // early start of the leading block's eigen-solve on the helper stream, next to the (first) persistent launch (k_early.hip);
         // D and E carry the sentinel from the previous solve's k_tri_sort, or are filled here
-        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !(tri_env("MOPT_TRI_EARLY") && atoi(tri_env("MOPT_TRI_EARLY")) == 0);
+        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !serialized_dispatch() &&
+                               !(tri_env("MOPT_TRI_EARLY") && atoi(tri_env("MOPT_TRI_EARLY")) == 0);
         if (use_early) {
             const size_t need = (size_t)batch * (MOPT_EARLY_STAGE * 8 + 8);
             if (ctx->early_bytes < need) {
@@ -2528,7 +2539,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         unsigned *word = (unsigned *)ctx->arena;                 // (head of the arena: zeroed when it is allocated)
         hipLaunchKernelGGL(k_dc_signal, dim3(1), dim3(64), 0, ctx->side3, word, epoch);
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join5, ctx->side3));      // (waited for at the start of the next solve: the chain reads this solve's buffers)
-        if (tri_env("MOPT_TRI_DCJOIN") && atoi(tri_env("MOPT_TRI_DCJOIN")) == 1) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
+        if (serialized_dispatch() || (tri_env("MOPT_TRI_DCJOIN") && atoi(tri_env("MOPT_TRI_DCJOIN")) == 1)) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
         else hipLaunchKernelGGL(k_dc_wait, dim3(1), dim3(64), 0, ctx->stream, batch, (const int *)d_dcflag, (const unsigned *)word, epoch, d_fail);
     }
     if (bt_mfma) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the T factors (side stream)
