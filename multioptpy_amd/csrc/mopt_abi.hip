@@ -334,6 +334,7 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
                                                     si, si + nvi, si + 2 * nvi, si + 4 * nvi, si + 4 * nvi + 2 * batch, dW.as<double>(), dperm.as<int>(),
                                                     dinfo.as<int>(), dG.as<double>());
             ctx->tri_no_persist = saved;
+            ctx->early_clean = nullptr;                      // (the scratch of this call is freed below: k_tri_early's sentinel bookkeeping is per address)
             if (rc != MOPT_OK) return rc;
             MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         } else

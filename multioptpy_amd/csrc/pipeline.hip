@@ -3,6 +3,8 @@
 #include "pipeline.h"
 
 RsirfoWork::~RsirfoWork() {
+    // (the sentinel bookkeeping of k_tri_early is per address: memory that goes back to the allocator is not "known clean" any more)
+    if (ctx && block && ctx->early_clean == (const void *)tri.D) ctx->early_clean = nullptr;
     if (block) hipFree(block);
 }
 
