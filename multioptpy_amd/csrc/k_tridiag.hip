@@ -1366,6 +1366,17 @@ __device__ __forceinline__ int sturm_count(const double *d, const double *e2, in
     return cnt;
 }
 
+// developer check (MOPT_TRI_EARLYDBG): D, E must be complete behind the tridiagonalisation
+__global__ void k_dbg_sentinel(int n, const double *D_, const double *E_, int where) {
+    const int b = blockIdx.x;
+    int cnt = 0, firsti = -1;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const unsigned long long du = ((const unsigned long long *)D_)[(size_t)b * n + i], eu = ((const unsigned long long *)E_)[(size_t)b * n + i];
+        if (du == ~0ull || eu == ~0ull) { ++cnt; if (firsti < 0) firsti = i; }
+    }
+    if (cnt) printf("[sentinel] at %d: matrix %d thread %d sees %d entries still holding the sentinel, first at row %d\n", where, b, (int)threadIdx.x, cnt, firsti);
+}
+
 // Device-side join with the divide-and-conquer chain.  The chain is enqueued on every call and takes ~100 us on its helper stream even
 // when no matrix is flagged (~25 launches that return at once); a stream-level join made the back-transformation wait for that.
 // k_dc_signal ends the chain and publishes the call's epoch; k_dc_wait (main stream, one wave) returns at once when no matrix of the
@@ -1659,7 +1670,7 @@ __global__ void __launch_bounds__(MAXM * 2) k_tri_small(int n, const double *__r
 // max-norm for the iteration.  Same contract as k_tri_small: WT[s .. t) and rows s .. t-1 of Zt (zero outside the block).
 __global__ void __launch_bounds__(64) k_tri_ql32(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
                                                  const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_, int *__restrict__ fail_,
-                                                 const int *__restrict__ dcflag_, const double *__restrict__ stage_, const int *__restrict__ early_) {
+                                                 const int *__restrict__ dcflag_, const double *__restrict__ stage_, const int *__restrict__ early_, int early_dbg) {
     __shared__ double Zs[32 * 32];
     if (dcflag_ && dcflag_[blockIdx.y]) return;
     const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;
@@ -1673,6 +1684,11 @@ __global__ void __launch_bounds__(64) k_tri_ql32(int n, const double *__restrict
         // the leading block was solved by k_tri_early (k_early.hip) while the tridiagonalisation was still running
         const double *stage = stage_ + (size_t)b * MOPT_EARLY_STAGE;
         d = (lane < m) ? stage[lane] : 0.0;
+        if (early_dbg) {                                     // developer check: trace of the block against the staged eigenvalue sum
+            double tr = (lane < m) ? D[lane] : 0.0, sv = (lane < m) ? d : 0.0;
+            tr = wave_sum(tr); sv = wave_sum(sv);
+            if (lane == 0 && fabs(tr - sv) > 1e-9 * (1.0 + fabs(tr))) printf("[early] matrix %d block %d: trace %.15g, staged eigenvalue sum %.15g\n", b, m, tr, sv);
+        }
         for (int i = lane; i < 32 * m; i += WAVE) Zs[i] = stage[32 + i];
         __syncthreads();
     } else {
@@ -2264,8 +2280,24 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;
         // early start of the leading block's eigen-solve on the helper stream, next to the (first) persistent launch (k_early.hip);
         // D and E carry the sentinel from the previous solve's k_tri_sort, or are filled here
-        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !serialized_dispatch() &&
-                               !(tri_env("MOPT_TRI_EARLY") && atoi(tri_env("MOPT_TRI_EARLY")) == 0);
+        // The watcher wave shares a CU with one member of the group and slows it down.  A member that still owns live rows cannot fall behind
+        // (the others wait for its products), but one whose rows have all been eliminated only consumes the exchange: two steps behind, it
+        // finds its tagged words overwritten and times out (measured: 8 matrices of n = 120 on groups of 32 -- 17 of 32 members own no
+        // row at all -- lost a matrix every third solve with the watcher, never without).  The early start is therefore taken only when
+        // every member keeps live rows for the ~160 steps the watcher may be busy (n = 300 on groups of 8: the first member runs dry at
+        // step 247); MOPT_TRI_EARLY=2 forces it.
+        int dry_step = n;
+        {
+            const int nch = (n + TRI_RC - 1) / TRI_RC;
+            for (int g = 0; g < G; ++g) {
+                const int c_last = (g < nch) ? g + G * ((nch - 1 - g) / G) : -1;
+                const int last_row = c_last < 0 ? -1 : std::min(n, (c_last + 1) * TRI_RC) - 1;
+                dry_step = std::min(dry_step, last_row);
+            }
+        }
+        const int early_env = tri_env("MOPT_TRI_EARLY") ? atoi(tri_env("MOPT_TRI_EARLY")) : 1;
+        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !serialized_dispatch() && early_env != 0 &&
+                               (early_env == 2 || dry_step >= std::min(n - 2, 160));
         if (use_early) {
             const size_t need = (size_t)batch * (MOPT_EARLY_STAGE * 8 + 8);
             if (ctx->early_bytes < need) {
@@ -2277,10 +2309,11 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             }
             early_stage = (double *)ctx->early_buf;
             early_flag = (int *)((char *)ctx->early_buf + (size_t)batch * MOPT_EARLY_STAGE * 8);
-            if (!early_was_clean) {
+            if (!early_was_clean || tri_env("MOPT_TRI_EARLYMEMSET")) {
                 MOPT_HIP_TRY(ctx, hipMemsetAsync(d_D, 0xFF, (size_t)batch * n * 8, ctx->stream));
                 MOPT_HIP_TRY(ctx, hipMemsetAsync(d_E, 0xFF, (size_t)batch * n * 8, ctx->stream));
             }
+            if (tri_env("MOPT_TRI_EARLYDBG")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_TAU, 0xFF, (size_t)batch * n * 8, ctx->stream));
             clr_D = d_D; clr_E = d_E;                         // (k_tri_sort leaves the sentinel behind this solve)
             MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork4, ctx->stream));
             MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork4, 0));
@@ -2474,6 +2507,10 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
                                       (char *)ctx->arena + 256);
         if (rc != MOPT_OK) return rc;
     }
+    if (tri_env("MOPT_TRI_EARLYDBG")) {
+        hipLaunchKernelGGL(k_dbg_sentinel, dim3(batch), dim3(64), 0, ctx->stream, n, d_D, d_E, 1);
+        hipLaunchKernelGGL(k_dbg_sentinel, dim3(batch), dim3(64), 0, ctx->stream, n, d_TAU, d_TAU, 2);
+    }
     {
         mopt_scope sc(ctx, "eigh_bisect", 1);
         hipLaunchKernelGGL(k_tri_bisect, dim3((n + BIS_PER_WG - 1) / BIS_PER_WG, batch), dim3(BIS_THREADS), (size_t)3 * n * 8 + (size_t)2 * n * 4,
@@ -2492,7 +2529,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             const bool use_ql = !(tri_env("MOPT_TRI_QL") && atoi(tri_env("MOPT_TRI_QL")) == 0);
             if (small_max > 0 && use_ql)
                 hipLaunchKernelGGL(k_tri_ql32, dim3(n, batch), dim3(64), 0, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag,
-                                   (const double *)early_stage, (const int *)early_flag);
+                                   (const double *)early_stage, (const int *)early_flag, tri_env("MOPT_TRI_EARLYDBG") ? 1 : 0);
             else if (small_max > 0)
                 hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
             if (small_max > 32)

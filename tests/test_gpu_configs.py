@@ -77,6 +77,35 @@ def test_band_fused_chain_matches_unfused_and_unsymmetric_upload():
     assert np.array_equal(outs[0], outs[0].T)                 # the fused path keeps the resident Hessians bitwise symmetric
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["identity", "exact"])
+def test_band_step_overlap_switches_agree(exact):
+    """The overlapped form of a band step -- scalar RFO stage next to the back-transformation through g~ = Z^T (Q^T g) (k_applyq.hip),
+    early start of the leading block next to the persistent tridiagonalisation (k_early.hip), device-side join with the
+    divide-and-conquer chain -- against the oracle and against the same steps with each mechanism switched off (and with all
+    cross-stream waits off, as under a profiler that serialises kernels): 8 images x 40 atoms (n = 120: persistent kernel, blocked
+    back-transformation), six steps, from identity and from exact Hessians (dense spectra: the D&C chain does the work)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests')); "
+            "sys.path.insert(0, os.path.join(os.getcwd(), 'tests', 'golden')); import numpy as np, test_gpu_configs as t; "
+            "w, H = t._run_band(8, 40, 6, sys.argv[2] == '1'); np.save(sys.argv[1], H); print(w)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for tag, env in (("default", {}), ("no-overlap", {"MOPT_RFO_OVERLAP": "0"}), ("no-early", {"MOPT_TRI_EARLY": "0"}),
+                     ("stream-join", {"MOPT_TRI_DCJOIN": "1"}), ("serialised", {"MOPT_SERIALIZED": "1"})):
+        f = os.path.join("/tmp", f"mopt_sw_{tag}_{os.getpid()}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f, "1" if exact else "0"], env=dict(os.environ, **env), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, (tag, r.stderr[-2000:])
+        outs[tag] = np.load(f)
+        os.remove(f)
+        print(tag, "worst deviation from the oracle over six steps:", r.stdout.strip().splitlines()[-1])
+    for tag, H in outs.items():
+        d = np.abs(H - outs["default"]).max()
+        print(tag, "Hessian of the middle image vs default:", d)
+        assert d < 1e-10, (tag, d)
+
+
 def test_band_64x200_vs_oracle():
     """BASELINE config 5's shape (64 images x 200 atoms, n = 600): two band steps against the oracle (closed-form BNEB
     projection; the oracle's literal SVD form needs minutes at this size and is pinned at N <= 14 by G6)."""
