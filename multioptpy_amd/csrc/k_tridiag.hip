@@ -1279,7 +1279,13 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
         return true;
     };
+    // Last row this member owns.  Once the pivot has passed it the member has nothing left to compute or to publish -- and nothing
+    // holds the others back for it any more, so a member that only consumed the exchange could fall two steps behind and find its
+    // tagged words overwritten (time-out).  It leaves instead; member 0 stays, it stores the results of every step.
+    int my_last_row = -1;
+    for (int r = 0; r < rows_cap; ++r) { const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC); if (gi < n && gi > my_last_row) my_last_row = gi; }
     for (; k <= k_last; ++k) {
+        if (g != 0 && my_last_row <= k + 1) break;           // (uniform over the workgroup)
         const int lo3 = k + 1 - 3;                           // a chunk is skipped once it has been dead for three steps
         int qd = lo3 < 0 ? 0 : lo3 >> 6;
         if (qd > CH - 1) qd = CH - 1;
