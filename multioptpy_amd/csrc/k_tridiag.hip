@@ -1047,6 +1047,15 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         }
     }
     __syncthreads();
+    // Last row this member owns.  Once the pivot has passed it the member has nothing left to compute or to publish -- and nothing
+    // holds the others back for it any more, so a member that only consumed the exchange could fall two steps behind and find its
+    // tagged words overwritten (time-out).  It leaves instead; the results of a step are stored by a member that is still live.
+    int my_last_row = -1, last_row0 = -1;
+    for (int r = 0; r < rows_cap; ++r) {
+        const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC), g0i = ((r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+        if (gi < n && gi > my_last_row) my_last_row = gi;
+        if (g0i < n && g0i > last_row0) last_row0 = g0i;
+    }
     double tau = 0.0;                                        // (wave 0) tau of the reflector in sv
     int vi0 = 0;                                             // v buffer of step k: (k + 1) % 3, kept incrementally
     int k = -1;
@@ -1144,7 +1153,8 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 svn[lo + 1] = 1.0;                           // (behind the vector stores: LDS operations of a wave stay in order)
                 // D, E, TAU of this step: left in LDS for the last wave, which stores them (and the reflector) behind its rows --
                 // workgroup 0 is on the critical path of every step and its wave 0 should carry nothing the others do not
-                if (g == 0) { double *mb = s_mail + 4 * (nxt & 1); mb[0] = diag; mb[1] = betan; mb[2] = taun; }
+                // (member 0 while it stores the results; every member once that duty moves around, see below)
+                if (g == 0 || lo + 1 >= last_row0) { double *mb = s_mail + 4 * (nxt & 1); mb[0] = diag; mb[1] = betan; mb[2] = taun; }
             }
             tau = taun;
             }
@@ -1267,7 +1277,20 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 }
             }
         }
-        if (g == 0 && wid == NWV - 1) {                      // results of the step for the host side: reflector (row lo, dsytrd layout), D, E, TAU
+        // Results of the step for the host side: reflector (row lo, dsytrd layout), D, E, TAU.  Every member forms them (the prologue is
+        // redundant); they are stored by a member with live rows, hence one the others cannot outrun (see the note at the loop), and not
+        // the one that has to publish the pivot row of this step.
+        // Among the live members the one with the most slack: its chunk of the current round of the deal is already eliminated (one live
+        // chunk fewer than the members at and behind the pivot chunk) -- the role member 0 had for most of the run when it stored everything.
+        int store_g = 0;                                     // member 0 as long as it has live rows (it always has the most slack: its chunk of a round goes first)
+        if (lo + 1 >= last_row0) {
+            const int cp = (lo + 1) / TRI_RC, nch_ = (n + TRI_RC - 1) / TRI_RC;
+            int j = cp + G - nch_ + 1;                       // smallest j >= 1 with chunk cp - j + G still inside the matrix
+            if (j < 1) j = 1;
+            if (j < G && j <= cp) store_g = (cp - j) % G;
+            else { const int srow = (lo + 1 + TRI_RC < n) ? lo + 1 + TRI_RC : n - 1; store_g = (srow / TRI_RC) % G; }
+        }
+        if (g == store_g && wid == NWV - 1) {
 #pragma unroll
             for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj >= lo + 2 && jj < n) A[(size_t)lo * n + jj] = svn[jj]; }
             if (lane == 0) {
@@ -1279,13 +1302,8 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
         return true;
     };
-    // Last row this member owns.  Once the pivot has passed it the member has nothing left to compute or to publish -- and nothing
-    // holds the others back for it any more, so a member that only consumed the exchange could fall two steps behind and find its
-    // tagged words overwritten (time-out).  It leaves instead; member 0 stays, it stores the results of every step.
-    int my_last_row = -1;
-    for (int r = 0; r < rows_cap; ++r) { const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC); if (gi < n && gi > my_last_row) my_last_row = gi; }
     for (; k <= k_last; ++k) {
-        if (g != 0 && my_last_row <= k + 1) break;           // (uniform over the workgroup)
+        if (my_last_row <= k + 1) break;                     // (uniform over the workgroup)
         const int lo3 = k + 1 - 3;                           // a chunk is skipped once it has been dead for three steps
         int qd = lo3 < 0 ? 0 : lo3 >> 6;
         if (qd > CH - 1) qd = CH - 1;
@@ -2286,24 +2304,11 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;
         // early start of the leading block's eigen-solve on the helper stream, next to the (first) persistent launch (k_early.hip);
         // D and E carry the sentinel from the previous solve's k_tri_sort, or are filled here
-        // The watcher wave shares a CU with one member of the group and slows it down.  A member that still owns live rows cannot fall behind
-        // (the others wait for its products), but one whose rows have all been eliminated only consumes the exchange: two steps behind, it
-        // finds its tagged words overwritten and times out (measured: 8 matrices of n = 120 on groups of 32 -- 17 of 32 members own no
-        // row at all -- lost a matrix every third solve with the watcher, never without).  The early start is therefore taken only when
-        // every member keeps live rows for the ~160 steps the watcher may be busy (n = 300 on groups of 8: the first member runs dry at
-        // step 247); MOPT_TRI_EARLY=2 forces it.
-        int dry_step = n;
-        {
-            const int nch = (n + TRI_RC - 1) / TRI_RC;
-            for (int g = 0; g < G; ++g) {
-                const int c_last = (g < nch) ? g + G * ((nch - 1 - g) / G) : -1;
-                const int last_row = c_last < 0 ? -1 : std::min(n, (c_last + 1) * TRI_RC) - 1;
-                dry_step = std::min(dry_step, last_row);
-            }
-        }
+        // (The watcher wave shares a CU with one member of the group and slows it down.  That used to be fatal for groups in which some
+        // members had run out of rows -- pure consumers of the exchange are not flow-controlled -- and is harmless since such members leave
+        // the kernel, see k_tri_persist3: 8 matrices of n = 120 on groups of 32 lost a matrix in every third solve before, none in 40 after.)
         const int early_env = tri_env("MOPT_TRI_EARLY") ? atoi(tri_env("MOPT_TRI_EARLY")) : 1;
-        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !serialized_dispatch() && early_env != 0 &&
-                               (early_env == 2 || dry_step >= std::min(n - 2, 160));
+        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !serialized_dispatch() && early_env != 0;
         if (use_early) {
             const size_t need = (size_t)batch * (MOPT_EARLY_STAGE * 8 + 8);
             if (ctx->early_bytes < need) {
