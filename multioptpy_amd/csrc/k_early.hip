@@ -88,7 +88,7 @@ int mopt_launch_tri_early(mopt_ctx *ctx, hipStream_t st, int n, int batch, const
                           double *d_stage, int *d_early) {
     using namespace mopt;
     MOPT_HIP_TRY(ctx, hipMemsetAsync(d_early, 0, (size_t)batch * sizeof(int), st));
-    hipLaunchKernelGGL(k_tri_early, dim3(8 * batch), dim3(64), 0, st, n, batch, d_D, d_E, (const unsigned long long *)d_xch, xch_stride_u64, d_stage, d_early, 30000u);      // (~30 ms of polling at most)
+    hipLaunchKernelGGL(k_tri_early, dim3(8 * batch), dim3(64), 0, st, n, batch, d_D, d_E, (const unsigned long long *)d_xch, xch_stride_u64, d_stage, d_early, 2500u);      // (a few ms of polling at most: the rows it needs are there after ~100 us)
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }
