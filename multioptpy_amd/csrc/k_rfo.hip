@@ -28,6 +28,12 @@ __global__ void __launch_bounds__(256) k_vtg(int n, const double *__restrict__ V
     if (lane == 0) gt_all[(size_t)b * n + i] = d;
 }
 
+// WaveRed with a wave-level sync(): for the section of k_rfo_scalar in which the three waves of the workgroup run different solves
+// (a workgroup barrier there would have to be reached equally often by all three)
+struct WaveRedLocal : WaveRed {
+    __device__ void sync() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+};
+
 // rsirfo.py:492-551 on an ascending array (wave-parallel)
 __device__ inline bool ill_conditioned(const WaveRed &red, const double *w, int n, double thresh) {
     if (n < 2) return false;
@@ -44,8 +50,10 @@ __device__ inline bool ill_conditioned(const WaveRed &red, const double *w, int 
     return (mx / mn) > thresh;
 }
 
-// dynamic LDS: 9 * n doubles + 3 * n ints
-__global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_params *__restrict__ params,
+// Three waves per image: all of them run the (cheap, identical) set-up; then wave 0 solves the RFO equations for alpha0 while waves 1 and 2
+// solve them for the two bracket values of alpha (1e-6, alpha_max) -- three of the five secular solves of a step side by side --
+// and wave 0 finishes alone (logic.h rs_step_rest).  dynamic LDS: 15 * n doubles + 3 * n ints
+__global__ void __launch_bounds__(192) k_rfo_scalar(int n, const mopt_rsirfo_params *__restrict__ params,
                                                    mopt_rsirfo_state *__restrict__ states, const double *__restrict__ W,
                                                    const int *__restrict__ perm, const int *__restrict__ einfo,
                                                    const double *__restrict__ gt_all_, const double *__restrict__ Bg,
@@ -54,7 +62,8 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     extern __shared__ __attribute__((aligned(16))) double sm[];
     // one latency-bound wave per image, usually running next to the back-transformation (pipeline.hip): highest issue priority on its SIMD
     __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ double s_n2[2];
     double *w0 = sm;             // [n] eigenvalues of the projected Hessian (ascending)
     double *g0 = w0 + n;         // [n] v_i . g in that order
     double *ws = g0 + n;         // [n] image-function eigenvalues, ascending, filtered (first m entries)
@@ -64,7 +73,8 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     double *fac = best + n;      // [n] sign factor of the image function per sorted position (1, -1 or 0)
     double *cg2 = fac + n;       // [n] (g'/alpha)^2 of the current secular solve
     double *cw = cg2 + n;        // [n] lambda'/alpha of the current secular solve
-    int *vidx = (int *)(cw + n);         // [n] eigenvector (Vt row) of sorted position k
+    double *ex = cw + n;         // [2][3][n] cg2, cw, step of the bracket solves (waves 1, 2)
+    int *vidx = (int *)(ex + 6 * n);     // [n] eigenvector (Vt row) of sorted position k
     int *kidx = vidx + n;                // [n] sorted position k of kept entry
     const WaveRed red;
     const long long tp0 = dbg ? wall_clock64() : 0;
@@ -203,7 +213,23 @@ __global__ void __launch_bounds__(64) k_rfo_scalar(int n, const mopt_rsirfo_para
     // --- RS step (rsirfo.py:924-984)
     RsResult rr;
     rr.branch = 0; rr.alpha = p.alpha0; rr.lambda_aug0 = 0.0; rr.initial_norm = 0.0; rr.secular_iters0 = 0;
-    if (m > 0) rr = rs_step(red, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw);
+    {
+        // (up to here all three waves have computed the same things; m, ws, gs are complete behind the barrier above)
+        const WaveRedLocal redl;
+        double lam0 = 0.0, n2_0 = 0.0;
+        int its0 = 0;
+        if (m > 0) {
+            if (wid == 0) lam0 = solve_rfo(redl, ws, gs, m, p.alpha0, stp, &n2_0, &its0, cg2, cw);
+            else {
+                double *c2 = ex + (size_t)(wid - 1) * 3 * n, *cwx = c2 + n, *stx = cwx + n, q;
+                solve_rfo(redl, ws, gs, m, wid == 1 ? 1e-6 : p.alpha_max, stx, &q, nullptr, c2, cwx);
+                if (lane == 0) s_n2[wid - 1] = q;
+            }
+        }
+        __syncthreads();
+        if (wid != 0) return;                                // (wave 0 alone from here on: the barriers below are its own)
+        if (m > 0) rr = rs_step_rest(red, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw, lam0, n2_0, its0, &s_n2[0], &s_n2[1]);
+    }
     __syncthreads();
     if (dbg) tp3 = wall_clock64();
     // --- finite check (rsirfo.py:455-463) and steepest-descent fallback in the full eigenbasis
@@ -285,9 +311,9 @@ int mopt_launch_rfo_scalar(mopt_ctx *ctx, hipStream_t st, int n, int batch, cons
                            const mopt::UpdateCoef *d_coef, double *d_coefout) {
     using namespace mopt;
     static const int dbg = getenv("MOPT_RFO_DBG") ? 1 : 0;
-    const size_t lds = (size_t)9 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
+    const size_t lds = (size_t)15 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
     if (lds > 48000) MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-    hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(64), lds, st, n, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout, dbg);
+    hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(192), lds, st, n, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout, dbg);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

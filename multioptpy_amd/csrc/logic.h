@@ -459,18 +459,33 @@ struct RsResult {
     int secular_iters0;
 };
 
+template <class R>
+MOPT_HD RsResult rs_step_rest(const R &red, const mopt_rsirfo_params &p, double trust_radius, const double *w, const double *gt, int m, double *step,
+                              double *best, double *cg2, double *cw, double lam0, double n2_0, int its0, const double *pre_lo, const double *pre_hi);
+
 // get_rs_step + compute_rsprfo_step (rsirfo.py:924-1248) in the eigenbasis.
 // w, gt: the m kept eigenvalues / transformed gradient; step: output (m); best: scratch (m).
 template <class R>
 MOPT_HD RsResult rs_step(const R &red, const mopt_rsirfo_params &p, double trust_radius, const double *w,
                          const double *gt, int m, double *step, double *best, double *cg2 = nullptr, double *cw = nullptr) {
-    RsResult rr;
-    rr.branch = 0; rr.alpha = p.alpha0; rr.secular_iters0 = 0;
     double n2;
     int its = 0;
-    rr.lambda_aug0 = solve_rfo(red, w, gt, m, p.alpha0, step, &n2, &its, cg2, cw);
-    rr.secular_iters0 = its;
-    rr.initial_norm = sqrt(n2);
+    const double lam0 = solve_rfo(red, w, gt, m, p.alpha0, step, &n2, &its, cg2, cw);
+    return rs_step_rest(red, p, trust_radius, w, gt, m, step, best, cg2, cw, lam0, n2, its, nullptr, nullptr);
+}
+
+// Everything behind the first solve (lambda_aug, ||step||^2 and iteration count of solve_rfo(alpha0) are handed in; `step` holds that
+// step).  pre_lo / pre_hi: ||step||^2 of the two bracket solves (alpha = 1e-6 and alpha_max) when the caller has formed them already --
+// k_rfo_scalar runs them on two further waves next to the first solve; they are independent of it, and the step they would leave in
+// `step` is formed again by the first micro cycle.
+template <class R>
+MOPT_HD RsResult rs_step_rest(const R &red, const mopt_rsirfo_params &p, double trust_radius, const double *w, const double *gt, int m, double *step,
+                              double *best, double *cg2, double *cw, double lam0, double n2_0, int its0, const double *pre_lo, const double *pre_hi) {
+    RsResult rr;
+    rr.branch = 0; rr.alpha = p.alpha0;
+    rr.lambda_aug0 = lam0;
+    rr.secular_iters0 = its0;
+    rr.initial_norm = sqrt(n2_0);
     const double R_ = trust_radius;
     if (rr.initial_norm <= R_) return rr;
 
@@ -478,10 +493,10 @@ MOPT_HD RsResult rs_step(const R &red, const mopt_rsirfo_params &p, double trust
     double alpha = p.alpha0;
     {
         double n2lo, n2hi;
-        solve_rfo(red, w, gt, m, 1e-6, step, &n2lo, nullptr, cg2, cw);
+        if (pre_lo) n2lo = *pre_lo; else solve_rfo(red, w, gt, m, 1e-6, step, &n2lo, nullptr, cg2, cw);
         double nlo = sqrt(n2lo);
         double obj_lo = nlo * nlo - R_ * R_;
-        solve_rfo(red, w, gt, m, p.alpha_max, step, &n2hi, nullptr, cg2, cw);
+        if (pre_hi) n2hi = *pre_hi; else solve_rfo(red, w, gt, m, p.alpha_max, step, &n2hi, nullptr, cg2, cw);
         double nhi = sqrt(n2hi);
         double obj_hi = nhi * nhi - R_ * R_;
         if (obj_lo * obj_hi < 0.0) {
