@@ -463,8 +463,9 @@ int mopt_band_step_phase_a(mopt_band *b, int optimize_num) {
         b->fused_step = fused;
         if (fused) BTRY(mopt_launch_trrot_basis_side(ctx, n, count, b->X + (size_t)first * n, wk.Q));
     }
-    // (a fill node, not a copy from a host buffer: the step enqueues without waiting for the stream)
-    MOPT_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)wk.do_update, have_prev ? 1 : 0, (size_t)count, ctx->stream));
+    // (a fill node, not a copy from a host buffer: the step enqueues without waiting for the stream; the fused chain takes the flag as a
+    // kernel argument instead)
+    if (!b->fused_step) MOPT_HIP_TRY(ctx, hipMemsetD32Async((hipDeviceptr_t)wk.do_update, have_prev ? 1 : 0, (size_t)count, ctx->stream));
     // 1. NEB force.  Whole band on one device: all images (FIRE's switch sums over all of F).  Image-sharded: the owned images;
     //    the switch is assembled from per-rank partial sums.
     if (!sharded) {
@@ -495,7 +496,7 @@ int mopt_band_step_phase_b(mopt_band *b, int optimize_num) {
         hipLaunchKernelGGL(k_gamma, dim3(count), dim3(256), 0, ctx->stream, I, n, first, b->X, b->E, b->G, b->tau, b->gamma);
         if (!fused) hipLaunchKernelGGL(k_rank1, dim3((n + 7) / 8, count), dim3(256), 0, ctx->stream, n, first, b->gamma, b->tau, wk.H);
     }
-    const mopt::FusedBand fb = {b->gamma, b->tau, first};
+    const mopt::FusedBand fb = {b->gamma, b->tau, first, have_prev ? 1 : 0, false};
     // 3. per-image RSIRFO.run with B_g = g = biased gradient, energies 0.0 (rfo_neb.py:159-166)
     double *sx = wk.x, *sbg = wk.bg, *sg = wk.g, *spx = wk.px, *spg = wk.pg;
     wk.x = b->X + (size_t)first * n; wk.bg = b->G + (size_t)first * n; wk.g = wk.bg;

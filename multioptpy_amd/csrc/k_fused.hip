@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256) k_fused_mv7(int n, const double *__restri
 // global loads (all in flight together); the four dependent phases after that -- dots, coefficients, W, W' -- touch LDS only and the
 // results leave in one round of stores.  Dynamic LDS: 18 n doubles (t, s, y, u, y', a: 6 n; Q: 6 n; W: 6 n -- W0 is taken into W, x - px etc.
 // are formed on the way in) + the reduction scratch.
-__global__ void __launch_bounds__(512) k_fused_coef(int n, int guard_sy, int first, const int *__restrict__ rules, const int *__restrict__ do_update,
+__global__ void __launch_bounds__(512) k_fused_coef(int n, int guard_sy, int first, const int *__restrict__ rules, int upd_all,
                                                      const double *__restrict__ x_, const double *__restrict__ px_, const double *__restrict__ g_,
                                                      const double *__restrict__ pg_, const double *__restrict__ gamma_, const double *__restrict__ tau_,
                                                      const double *__restrict__ Q_, const double *__restrict__ u0_, const double *__restrict__ W0_,
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(512) k_fused_coef(int n, int guard_sy, int fir
     double *lt = fsm, *ls = lt + n, *ly = ls + n, *lu = ly + n, *lyd = lu + n, *la = lyd + n, *lq = la + n, *lw = lq + 6 * n;
     const double gam = gamma_[b];
     const int rule = rules[b];
-    const bool upd = !(do_update && !do_update[b]);
+    const bool upd = upd_all != 0;
     {
         const double *x = x_ + o, *px = px_ + o, *g = g_ + o, *pg = pg_ + o, *u0 = u0_ + o, *q = Q_ + (size_t)b * 6 * n;
         const double *t = tau_ + (size_t)(first + b) * n, *w0 = W0_ + (size_t)b * n * 6;
@@ -201,7 +201,15 @@ __device__ __forceinline__ double mul_r(double a, double b) { double p = a * b; 
 __global__ void __launch_bounds__(256) k_fused_final(int n, int first, double *__restrict__ H, double *__restrict__ A, const double *__restrict__ gamma_,
                                                      const double *__restrict__ tau_, const UpdateCoef *__restrict__ coef,
                                                      const double *__restrict__ yd_, const double *__restrict__ u_, const double *__restrict__ A_v,
-                                                     const double *__restrict__ s_, const double *__restrict__ Q_, const double *__restrict__ W_) {
+                                                     const double *__restrict__ s_, const double *__restrict__ Q_, const double *__restrict__ W_,
+                                                     int *__restrict__ fail_, unsigned long long *__restrict__ xch_, size_t xch_stride) {
+    // (what the eigen-solver needs zeroed before its persistent kernel starts -- failure flags, exchange area at the head of each slot of its
+    // eigenvector buffer -- is zeroed here instead of by two fill kernels in front of it; EighRfoHook::pre_cleared, pipeline.h)
+    if (blockIdx.x == 0 && fail_) {
+        if (threadIdx.x == 0) fail_[blockIdx.y] = 0;
+        unsigned long long *xp = xch_ + (size_t)blockIdx.y * xch_stride;
+        for (int i = threadIdx.x; i < 8 * n + 64; i += 256) xp[i] = 0ull;
+    }
     __shared__ double vr[17][32], vc[17][32];                // t, y', u, a, s, q[6], w'[6] of the tile's rows and of its columns
     const int T = (n + 31) / 32;
     const int bi = blockIdx.x / T, bj = blockIdx.x % T, b = blockIdx.y;
@@ -268,14 +276,14 @@ int mopt_launch_fused_update_project(mopt_ctx *ctx, RsirfoWork &wk, int n, int b
         if (lds > 60000) MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_fused_coef, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int nthr = ((n + 63) / 64) * 64;
         if (nthr > 512) nthr = 512;
-        hipLaunchKernelGGL(k_fused_coef, dim3(batch), dim3(nthr), lds, ctx->stream, n, 1, fb.first, wk.rules, wk.do_update, wk.x, wk.px, wk.g, wk.pg,
+        hipLaunchKernelGGL(k_fused_coef, dim3(batch), dim3(nthr), lds, ctx->stream, n, 1, fb.first, wk.rules, fb.upd_all, wk.x, wk.px, wk.g, wk.pg,
                            fb.gamma, fb.tau, wk.Q, wk.Hy, wk.Gt, wk.s, wk.y, wk.u, wk.yd, wk.Av, wk.coef, wk.info, wk.W6);
     }
     {
         mopt_scope sc(ctx, "project", 1);
         const int T = (n + 31) / 32;
         hipLaunchKernelGGL(k_fused_final, dim3(T * T, batch), dim3(256), 0, ctx->stream, n, fb.first, wk.H, wk.A, fb.gamma, fb.tau, wk.coef, wk.yd, wk.u,
-                           wk.Av, wk.s, wk.Q, wk.W6);
+                           wk.Av, wk.s, wk.Q, wk.W6, fb.clear_for_eigh ? wk.tri.fail : (int *)nullptr, (unsigned long long *)wk.Vt, (size_t)n * n);
     }
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;

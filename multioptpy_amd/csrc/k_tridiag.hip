@@ -2177,7 +2177,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
     const bool multi = !(tri_env("MOPT_TRI_SINGLE")) && n >= 32;
     const bool no_persist = ctx->tri_no_persist || tri_env("MOPT_TRI_NOPERSIST");
-    MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
+    const bool pre_cleared = hook && hook->pre_cleared;      // (failure flags and exchange area zeroed by the caller's last kernel)
+    if (!pre_cleared) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
     // persistent LDS-resident variant: G workgroups per matrix with rows_cap * n doubles of LDS each
     int G = 8;
     const int cols = ((n + 63) / 64) * 64;
@@ -2300,7 +2301,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         if (tri_env("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
         const size_t xwords = (size_t)8 * n + G;               // p vectors, pivot rows (two buffers each, two tagged words per value), XCC ids
-        MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
+        if (!(pre_cleared && xwords <= (size_t)8 * n + 64)) MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
         int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;
         // early start of the leading block's eigen-solve on the helper stream, next to the (first) persistent launch (k_early.hip);
         // D and E carry the sentinel from the previous solve's k_tri_sort, or are filled here

@@ -37,7 +37,9 @@ struct RsirfoWork {
 };
 
 // Band path, fused form (k_fused.hip): Ayala term gamma t t^T, quasi-Newton update and TR/rot projection in three launches.
-namespace mopt { struct FusedBand { const double *gamma; const double *tau; int first; }; }
+namespace mopt { struct FusedBand { const double *gamma; const double *tau; int first; int upd_all; bool clear_for_eigh; }; }
+/* upd_all: every image has a previous step (no per-image flags); clear_for_eigh: k_fused_final also zeroes the eigen-solver's failure flags and
+   exchange area (set by the pipeline when the reduction route follows -- on the Jacobi route Vt carries the warm-start vectors) */
 int mopt_launch_fused_update_project(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, const mopt::FusedBand &fb);
 
 // update (optional) -> TR/rot projections -> eigh -> RS-I-RFO step.  Hsym may alias wk.H (in-place).
@@ -81,6 +83,7 @@ int mopt_launch_dgemm(mopt_ctx *ctx, int n, int batch, const double *d_A, const 
 struct EighRfoHook {
     const double *gp = nullptr; double *gq = nullptr; hipEvent_t ev_gp = nullptr;
     double *vout = nullptr;
+    bool pre_cleared = false;      // the caller has zeroed d_fail and the first 8 n + 64 64-bit words of every matrix' slot of d_Vt (exchange area of the persistent kernel)
     void *user = nullptr;
     int (*front)(mopt_ctx *, void *user, hipStream_t st, const double *d_Zt, const double *d_gq) = nullptr;
     int (*scalar)(mopt_ctx *, void *user, hipStream_t st) = nullptr;

@@ -61,8 +61,11 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     }
     rc = mopt_launch_project_grad(ctx, n, batch, wk.bg, wk.x, wk.gp, 0, /*side_stream=*/true);      // joined in front of the RFO stage
     if (rc != MOPT_OK) return rc;
+    const bool clear_for_eigh = (fb != nullptr) && mopt_eigh_algo(n) == 1 && n * n >= 8 * n + 64;
     if (fb) {
-        rc = mopt_launch_fused_update_project(ctx, wk, n, batch, *fb);
+        mopt::FusedBand fbl = *fb;
+        fbl.clear_for_eigh = clear_for_eigh;
+        rc = mopt_launch_fused_update_project(ctx, wk, n, batch, fbl);
         if (rc != MOPT_OK) return rc;
         coef = wk.coef;
     } else if (any_update) {
@@ -81,6 +84,7 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     EighRfoHook hook;
     hook.gp = wk.gp; hook.gq = wk.Hy; hook.ev_gp = ctx->ev_join2; hook.user = &hu;
     hook.vout = wk.Gt;                                       // (free on the reduction route: the eigenvectors V land there, Z stays in wk.Vt)
+    hook.pre_cleared = clear_for_eigh;                       // k_fused_final has zeroed the failure flags and the exchange area
     hook.front = [](mopt_ctx *c, void *u, hipStream_t st, const double *d_Zt, const double *d_gq) -> int {
         HookUser *h = (HookUser *)u;
         mopt_scope sc(c, "rfo_scalar", 1, st);
