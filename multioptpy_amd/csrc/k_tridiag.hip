@@ -2309,7 +2309,12 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         // members had run out of rows -- pure consumers of the exchange are not flow-controlled -- and is harmless since such members leave
         // the kernel, see k_tri_persist3: 8 matrices of n = 120 on groups of 32 lost a matrix in every third solve before, none in 40 after.)
         const int early_env = tri_env("MOPT_TRI_EARLY") ? atoi(tri_env("MOPT_TRI_EARLY")) : 1;
-        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !serialized_dispatch() && early_env != 0;
+        // (the watcher needs room next to the persistent workgroup on every CU: 48 registers per lane and a wave slot per SIMD.  The 16-wave
+        // kernels of n <= 384 use ~52 of their 128 registers; the 8-wave kernels of n > 384 take all 256 -- the watcher would only start when
+        // the tridiagonalisation ends and add its time behind it: n = 600 single geometry 3.86 -> 4.10 ms)
+        bool early_fits = false;
+        { hipFuncAttributes fa; if (hipFuncGetAttributes(&fa, fn) == hipSuccess) early_fits = (size_t)fa.numRegs * (nthreads / 256) + 48 <= 512; }
+        const bool use_early = small_max_early > 0 && n > 40 && batch <= per && !serialized_dispatch() && early_env != 0 && (early_fits || early_env == 2);
         if (use_early) {
             const size_t need = (size_t)batch * (MOPT_EARLY_STAGE * 8 + 8);
             if (ctx->early_bytes < need) {
