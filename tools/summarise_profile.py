@@ -36,3 +36,10 @@ for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ns"]):
     fe = v["fetch"] / v["nf"] if v["nf"] else float("nan")
     wr = v["write"] / v["nw"] if v["nw"] else float("nan")
     print(f"{k[:40]:40s} {v['n']:9d} {v['ns'] / v['n'] / 1e3:10.2f} {100 * v['ns'] / tot:7.2f} {fe:16.1f} {wr:16.1f}")
+
+# whole-run totals of the counter passes (raw FETCH_SIZE is doubled: gfx950 counts wide reads at half their bytes)
+tf = sum(v["fetch"] for v in rows.values()); tw = sum(v["write"] for v in rows.values())
+steps = int(os.environ.get("MOPT_PROFILE_STEPS", "0"))
+if steps and (tf or tw):
+    print(f"\nall kernels of the run: FETCH {tf / 1024:.1f} MB raw, WRITE {tw / 1024:.1f} MB; per band step over {steps} steps (warm-up included): "
+          f"2 x FETCH + WRITE = {(2 * tf + tw) / 1024 / steps:.1f} MB")
