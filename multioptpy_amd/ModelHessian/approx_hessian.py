@@ -1,9 +1,10 @@
 """ApproxHessian: drop-in for ``multioptpy.ModelHessian.approx_hessian.ApproxHessian`` (reference approx_hessian.py:26-112).
 
 ``main(coord, element_list, cart_gradient, approx_hess_type)`` keeps the reference's signature (coord in bohr) and its dispatch by
-substring.  On the device: the Fischer + D3 model the reference's ``-modelhess`` switch selects by default
-(``fischerd3old``, interface.py:325-330; ModelHessian/fischerd3old.py:355-381) -- ``mopt_model_hessian`` of include/mopt_hip.h.
-Other model names raise NotImplementedError (they are not on the path this package accelerates); there is no CPU fallback.
+substring.  On the device (``mopt_model_hessian`` of include/mopt_hip.h): the Fischer + D3 model the reference's ``-modelhess``
+switch selects by default (``fischerd3old``, interface.py:325-330; ModelHessian/fischerd3old.py:355-381), the Fischer model with
+coordination-number scaled D3 pairs (``fischerd3``, ModelHessian/fischerd3.py:177-304) and the plain Fischer model (``fischer``,
+ModelHessian/fischer.py:216-236).  Other model names raise NotImplementedError; there is no CPU fallback.
 
 Per-element parameters (covalent radii, C6, van-der-Waals radii, r4/r2, D3 scaling) are the numbers the reference's
 ``multioptpy/Parameters`` functions return, kept as data in ``element_tables.json`` (tools/extract_element_tables.py)."""
@@ -16,7 +17,7 @@ import numpy as np
 from .. import _lib
 from .._lib import lib, check, f64, ptr
 
-MODEL_FISCHERD3OLD = 0
+MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER = 0, 1, 2
 _TAB = None
 
 
@@ -29,11 +30,11 @@ def _tables():
 
 
 def element_parameters(element_list):
-    """(par, d3): par = [cov | c6 | vdw | r4r2] as one (4 N,) array, d3 = (s6, s8, a1, a2) -- the arguments of the C ABI."""
+    """(par, d3): par = [cov | c6 | vdw | r4r2 | refcn] as one (5 N,) array, d3 = (s6, s8, a1, a2) -- the arguments of the C ABI."""
     t = _tables()
     el = t["elements"]
     try:
-        par = np.concatenate([np.array([el[str(e)][k] for e in element_list], dtype=np.float64) for k in ("cov", "c6", "vdw", "r4r2")])
+        par = np.concatenate([np.array([el[str(e)][k] for e in element_list], dtype=np.float64) for k in ("cov", "c6", "vdw", "r4r2", "refcn")])
     except KeyError as e:
         raise KeyError(f"no model-Hessian parameters for element {e}") from None
     d3 = np.array([t["d3"][k] for k in ("s6", "s8", "a1", "a2")], dtype=np.float64)
@@ -45,12 +46,21 @@ def model_kind(approx_hess_type):
     name = str(approx_hess_type).lower()
     if "gfnff" in name or "gfn0xtb" in name:
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device")
+    # the reference tests the substrings in this order (approx_hessian.py:41-91): fischerd3old, fischerd3, fischerd4, schlegel*, swart*,
+    # lindh*, fischer, morse
+    kind, base = None, None
     if "fischerd3old" in name:
-        for suffix in ("ts", "sr", "clip"):
-            if suffix in name.replace("fischerd3old", ""):
-                raise NotImplementedError(f"model Hessian modifier '{suffix}' is not available on the device")
-        return MODEL_FISCHERD3OLD
-    raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old)")
+        kind, base = MODEL_FISCHERD3OLD, "fischerd3old"
+    elif "fischerd3" in name:
+        kind, base = MODEL_FISCHERD3, "fischerd3"
+    elif not any(k in name for k in ("fischerd4", "schlegel", "swart", "lindh")) and "fischer" in name:
+        kind, base = MODEL_FISCHER, "fischer"
+    if kind is None:
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, fischer)")
+    for suffix in ("ts", "sr", "clip"):                  # approx_hessian.py:93-110: modifiers applied after the model
+        if suffix in name.replace(base, ""):
+            raise NotImplementedError(f"model Hessian modifier '{suffix}' is not available on the device")
+    return kind
 
 
 class ApproxHessian:

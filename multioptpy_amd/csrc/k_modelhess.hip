@@ -1,6 +1,12 @@
 // Model Hessian on the device: FischerD3ApproxHessianOld.main (multioptpy/ModelHessian/fischerd3old.py:355-381), the model the
 // reference's `-modelhess` switch selects by default (interface.py:325-330) and one of the two switches that turn the RFO-NEB
-// path on (neb.py:794-804, recomputed every -mfc steps per image: neb.py:515-523).
+// path on (neb.py:794-804, recomputed every -mfc steps per image: neb.py:515-523).  The same kernels carry the two other Fischer
+// models of ApproxHessian.main as a compile-free `kind` argument -- they differ in guards, in the connectivity table that excludes
+// pairs and counts torsion bonds, and in the pair term:
+//   MOPT_MODEL_FISCHERD3  FischerD3ApproxHessian.main (fischerd3.py:177-304): C6 of every atom scaled by its fractional coordination
+//                         number (fischerd3.py:46-60, 224-229; k_mh_connect), stricter guards (fischerd3.py:88, 144-155)
+//   MOPT_MODEL_FISCHER    FischerApproxHessian.main (fischer.py:216-236): no pair term, no angle guard, cross-product linearity test
+//                         of the torsions (fischer.py:140-170), no sin^2 damping
 //   k_mh_connect     distance tests -> two connectivity tables: 1.1 x covalent radii (BondConnectivity, Utils/bond_connectivity.py:
 //                    14-41: the internal coordinates) and 1.3 x (fischerd3old.py:136-154: torsion bond counts, D3 exclusions)
 //   k_mh_enumerate   bond / angle / dihedral tables in the reference's order (bond_connectivity.py:43-128; the dihedral rules depend
@@ -18,7 +24,8 @@ namespace mopt {
 
 struct MhWork {
     unsigned char *c11, *c13;     // [B][N][N]
-    int *nb13;                    // [B][N]
+    int *nb13;                    // [B][N] bonds per atom in the table the model counts torsion bonds with (1.3 x; fischerd3.py: 1.1 x)
+    double *c6s;                  // [B][N] C6 scaling of the atom (1 unless MOPT_MODEL_FISCHERD3)
     int *cnt;                     // [B][4]: bonds, angles, dihedrals, overflow flag
     int *atoms;                   // [B][cap][4]
     double *fc;                   // [B][cap]
@@ -27,26 +34,45 @@ struct MhWork {
     int cap, bcap, acap;
 };
 
-// X: [B][N][3]; par: cov[N], c6[N], vdw[N], r4r2[N]
-__global__ void __launch_bounds__(128) k_mh_connect(int N, const double *__restrict__ X_, const double *__restrict__ par, MhWork w) {
+// X: [B][N][3]; par: cov[N], c6[N], vdw[N], r4r2[N], refcn[N]
+__global__ void __launch_bounds__(128) k_mh_connect(int kind, int N, const double *__restrict__ X_, const double *__restrict__ par, MhWork w) {
     __shared__ int red[2];
+    __shared__ double cnp[128];
     const int b = blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
     const double *x = X_ + (size_t)b * N * 3, *cov = par;
     unsigned char *c11 = w.c11 + ((size_t)b * N + i) * N, *c13 = w.c13 + ((size_t)b * N + i) * N;
-    if (tid == 0) red[0] = 0;
+    if (tid < 2) red[tid] = 0;
     __syncthreads();
     const double xi = x[3 * i], yi = x[3 * i + 1], zi = x[3 * i + 2], ci = cov[i];
-    int n13 = 0;
+    int n13 = 0, n11 = 0;
+    double cn = 0.0;
     for (int j = tid; j < N; j += blockDim.x) {
         const double dx = x[3 * j] - xi, dy = x[3 * j + 1] - yi, dz = x[3 * j + 2] - zi;
         const double d = sqrt(dx * dx + dy * dy + dz * dz);
         const bool a = (j != i) && d <= (cov[j] + ci) * 1.1, c = (j != i) && d <= (ci + cov[j]) * 1.3;
         c11[j] = a ? 1 : 0; c13[j] = c ? 1 : 0;
-        n13 += c ? 1 : 0;
+        n13 += c ? 1 : 0; n11 += a ? 1 : 0;
+        if (kind == MOPT_MODEL_FISCHERD3) {
+            // "fractional coordination number" as fischerd3.py:46-60 computes it (k1 = 16, k2 = 4/3, exponent clipped to +-100).  With that
+            // sign the count tends to 1 for DISTANT atoms, and the diagonal (distance set to infinity, :53) adds exp(-100) -> 1 as well:
+            // reproduced as it is, the scaling of :226-227 is pinned by G10b.
+            const double t = (j == i) ? -100.0 : fmin(fmax(-16.0 * ((4.0 / 3.0) * (d / (ci + cov[j])) - 1.0), -100.0), 100.0);
+            cn += 1.0 / (1.0 + exp(t));
+        }
     }
-    atomicAdd(&red[0], n13);
+    atomicAdd(&red[0], n13); atomicAdd(&red[1], n11);
+    cnp[tid] = cn;
     __syncthreads();
-    if (tid == 0) w.nb13[(size_t)b * N + i] = red[0];
+    if (tid == 0) {
+        w.nb13[(size_t)b * N + i] = (kind == MOPT_MODEL_FISCHERD3) ? red[1] : red[0];
+        double sc = 1.0;
+        if (kind == MOPT_MODEL_FISCHERD3) {
+            double s = 0.0;
+            for (int t = 0; t < (int)blockDim.x; ++t) s += cnp[t];      // (fixed order: the result does not depend on scheduling)
+            sc = fmin(fmax(1.0 - 0.05 * (s - par[4 * (size_t)N + i]), 0.75), 1.25);      // fischerd3.py:226-227
+        }
+        w.c6s[(size_t)b * N + i] = sc;
+    }
 }
 
 // exclusive prefix sum of v[0 .. m) in place (one workgroup, m small: serial chunks per thread + block scan of the chunk sums)
@@ -168,7 +194,7 @@ __device__ inline double bend2(V3 x0, V3 x1, V3 x2, V3 bf[3]) {
 }
 
 // grid (ceil(cap / 64), B), block 64: one internal coordinate per lane
-__global__ void __launch_bounds__(64) k_mh_internals(int N, const double *__restrict__ X_, const double *__restrict__ par, MhWork w) {
+__global__ void __launch_bounds__(64) k_mh_internals(int kind, int N, const double *__restrict__ X_, const double *__restrict__ par, MhWork w) {
     const int b = blockIdx.y, e = blockIdx.x * 64 + threadIdx.x;
     const int *cnt = w.cnt + 4 * b;
     const int nb = cnt[0], na = cnt[1], nd = cnt[2];
@@ -181,13 +207,13 @@ __global__ void __launch_bounds__(64) k_mh_internals(int N, const double *__rest
     if (e < nb) {
         const int i = at[0], j = at[1];
         const double r = stretch2(ld3(x, i), ld3(x, j), bq[0], bq[1]);
-        fc = 0.3601 * exp(-1.944 * (r - (cov[i] + cov[j])));
+        fc = (kind == MOPT_MODEL_FISCHERD3 && r < 0.1) ? 0.0 : 0.3601 * exp(-1.944 * (r - (cov[i] + cov[j])));      // (fischerd3.py:88)
     } else if (e < nb + na) {
         const int i = at[0], j = at[1], k = at[2];
         const V3 vij = sub(ld3(x, i), ld3(x, j)), vjk = sub(ld3(x, k), ld3(x, j));
         const double rij = norm(vij), rjk = norm(vjk);
-        bool skip = (rij < 0.1 || rjk < 0.1);
-        if (!skip) skip = fabs(dot(vij, vjk) / (rij * rjk)) > 0.9999;
+        bool skip = (kind != MOPT_MODEL_FISCHER) && (rij < 0.1 || rjk < 0.1);      // (fischer.py:103-131 has no guard)
+        if (!skip && kind != MOPT_MODEL_FISCHER) skip = fabs(dot(vij, vjk) / (rij * rjk)) > 0.9999;
         if (!skip) {
             const double cij = cov[i] + cov[j], cjk = cov[j] + cov[k], val = cij * cjk;
             fc = (fabs(val) < 1e-10) ? 0.0 : 0.089 + 0.11 / pow(val, -0.42) * exp(-0.44 * (rij + rjk - cij - cjk));
@@ -202,13 +228,30 @@ __global__ void __launch_bounds__(64) k_mh_internals(int N, const double *__rest
         const double val = rjk * cjk;
         double f = (fabs(val) < 1e-10) ? 0.0 : 0.0015 + 14.0 * pow((double)max(bsum, 0), 0.57) / pow(val, 4.0) * exp(-2.85 * (rjk - cjk));
         const double nji = norm(vji), nkl = norm(vkl);
-        bool skip = (nji < 1e-8 || rjk < 1e-8 || nkl < 1e-8);
-        if (!skip) {
-            const double c1 = dot(vji, vjk) / (nji * rjk), c2 = -dot(vjk, vkl) / (rjk * nkl);
-            const double s1 = 1.0 - fmin(c1 * c1, 1.0), s2 = 1.0 - fmin(c2 * c2, 1.0);
-            skip = (s1 < 1e-4 || s2 < 1e-4);
+        bool skip;
+        double damp = 1.0;
+        if (kind == MOPT_MODEL_FISCHER) {
+            // fischer.py:140-170: sin^2 of the bond angles i-j-k and j-k-l from cross products, torsion dropped below 1e-3
+            auto sin2 = [&](V3 a, V3 c, V3 e2) {
+                const V3 v1 = sub(a, c), v2 = sub(e2, c);
+                const V3 cr = cross(v1, v2);
+                const double n1 = dot(v1, v1), n2 = dot(v2, v2);
+                return (n1 * n2 < 1e-12) ? 0.0 : dot(cr, cr) / (n1 * n2);
+            };
+            skip = sin2(xi, xj, xk) < 1e-3 || sin2(xj, xk, xl) < 1e-3;
+        } else {
+            const double tiny = (kind == MOPT_MODEL_FISCHERD3) ? 0.1 : 1e-8, lim = (kind == MOPT_MODEL_FISCHERD3) ? 1e-3 : 1e-4;      // fischerd3.py:144,154 / fischerd3old.py:262,276
+            skip = (nji < tiny || rjk < tiny || nkl < tiny);
             if (!skip) {
-                f *= s1 * s2;
+                const double c1 = dot(vji, vjk) / (nji * rjk), c2 = -dot(vjk, vkl) / (rjk * nkl);
+                const double s1 = 1.0 - fmin(c1 * c1, 1.0), s2 = 1.0 - fmin(c2 * c2, 1.0);
+                skip = (s1 < lim || s2 < lim);
+                damp = s1 * s2;
+            }
+        }
+        if (!skip) {
+            {
+                f *= damp;
                 // torsion2 (calc_params.py:139-178)
                 V3 bij0, bij1, bjk0, bjk1, bkl0, bkl1, t3[3];
                 const double r1 = stretch2(xi, xj, bij0, bij1), r2 = stretch2(xj, xk, bjk0, bjk1), r3 = stretch2(xk, xl, bkl0, bkl1);
@@ -220,6 +263,11 @@ __global__ void __launch_bounds__(64) k_mh_internals(int N, const double *__rest
                 bq[1] = scale(V3{ca * bq[0].x + cb * bq[3].x, ca * bq[0].y + cb * bq[3].y, ca * bq[0].z + cb * bq[3].z}, -1.0 / r2);
                 bq[2] = scale(V3{bq[0].x + bq[1].x + bq[3].x, bq[0].y + bq[1].y + bq[3].y, bq[0].z + bq[1].z + bq[3].z}, -1.0);
                 fc = f;
+                if (kind == MOPT_MODEL_FISCHERD3) {              // fischerd3.py:166: a torsion with non-finite B-vectors is dropped
+                    bool fin = true;
+                    for (int m = 0; m < 4; ++m) fin = fin && isfinite(bq[m].x) && isfinite(bq[m].y) && isfinite(bq[m].z);
+                    if (!fin) { fc = 0.0; for (int m = 0; m < 4; ++m) bq[m] = V3{0, 0, 0}; }
+                }
             }
         }
     }
@@ -228,7 +276,7 @@ __global__ void __launch_bounds__(64) k_mh_internals(int N, const double *__rest
 }
 
 // grid (N, B), block 128.  dynamic LDS: 9 N doubles (the 3 x 3N row block of atom m).  d3 = {s6, s8, a1, a2}
-__global__ void __launch_bounds__(128) k_mh_assemble(int N, const double *__restrict__ X_, const double *__restrict__ par, MhWork w, double s6, double s8,
+__global__ void __launch_bounds__(128) k_mh_assemble(int kind, int N, const double *__restrict__ X_, const double *__restrict__ par, MhWork w, double s6, double s8,
                                                      double a1, double a2, double *__restrict__ H_) {
     extern __shared__ __attribute__((aligned(16))) double row[];      // [3][3N]
     __shared__ double dsum[128][9];
@@ -266,14 +314,16 @@ __global__ void __launch_bounds__(128) k_mh_assemble(int N, const double *__rest
     }
     // ---- D3 pair blocks of the non-bonded (1.3 x) partners: H(m, j) -= blk, H(m, m) += blk
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const unsigned char *c13 = w.c13 + ((size_t)b * N + m) * N;
+    // pairs excluded by the 1.3 x table (fischerd3old.py:336) or by the 1.1 x table (fischerd3.py:196); none at all for MOPT_MODEL_FISCHER
+    const unsigned char *c13 = ((kind == MOPT_MODEL_FISCHERD3) ? w.c11 : w.c13) + ((size_t)b * N + m) * N;
+    const double *c6s = w.c6s + (size_t)b * N;
     const V3 xm = ld3(x, m);
-    for (int j = tid; j < N; j += nt) {
+    for (int j = tid; j < ((kind == MOPT_MODEL_FISCHER) ? 0 : N); j += nt) {
         if (j == m || c13[j]) continue;
         const V3 rv = sub(xm, ld3(x, j));
         const double r = norm(rv);
-        if (r < 0.1) continue;
-        const double c6ij = sqrt(c6[m] * c6[j]);
+        if ((kind == MOPT_MODEL_FISCHERD3) ? !(r > 0.1) : (r < 0.1)) continue;
+        const double c6ij = sqrt((c6[m] * c6s[m]) * (c6[j] * c6s[j]));
         const double c8ij = 3.0 * c6ij * sqrt(r4[m] * r4[j]);
         const double r0 = vdw[m] + vdw[j];
         const double r2_ = r * r, r5 = r2_ * r2_ * r, r6 = r5 * r, r7 = r6 * r, r8 = r7 * r, r9 = r8 * r, r10 = r9 * r;
@@ -309,35 +359,35 @@ __global__ void __launch_bounds__(128) k_mh_assemble(int N, const double *__rest
 
 }  // namespace mopt
 
-// d_X: [batch][N][3] bohr; d_par: cov[N], c6[N], vdw[N], r4r2[N] (atomic units); d3: s6, s8, a1, a2.  Result: d_A = the projected model Hessian
+// kind: MOPT_MODEL_*.  d_X: [batch][N][3] bohr; d_par: cov[N], c6[N], vdw[N], r4r2[N], refcn[N] (atomic units); d3: s6, s8, a1, a2.  Result: d_A = the projected model Hessian
 // (d_H holds the unprojected, unsymmetrised assembly).  d_Q, d_W: 6 n doubles per image.  Returns MOPT_E_ARG when an image has more
 // internal coordinates than the tables hold.
-int mopt_launch_model_hessian(mopt_ctx *ctx, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
+int mopt_launch_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
                               double *d_W, double *d_A, bool project) {
     using namespace mopt;
     const int n = 3 * N;
     MhWork w;
     w.bcap = 16 * N; w.acap = 96 * N; w.cap = w.bcap + w.acap + 192 * N;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t bytes = 2 * al((size_t)batch * N * N) + al((size_t)batch * N * 4) + al((size_t)batch * 16) + al((size_t)batch * w.cap * 16) +
+    const size_t bytes = 2 * al((size_t)batch * N * N) + al((size_t)batch * N * 4) + al((size_t)batch * N * 8) + al((size_t)batch * 16) + al((size_t)batch * w.cap * 16) +
                          al((size_t)batch * w.cap * 8) + al((size_t)batch * w.cap * 96) + al((size_t)batch * (w.cap + 2 * N + 8) * 4);
     char *blk = nullptr;
     MOPT_HIP_TRY(ctx, hipMalloc((void **)&blk, bytes));
     char *p = blk;
     auto take = [&](size_t x) { void *r = p; p += al(x); return r; };
     w.c11 = (unsigned char *)take((size_t)batch * N * N); w.c13 = (unsigned char *)take((size_t)batch * N * N);
-    w.nb13 = (int *)take((size_t)batch * N * 4); w.cnt = (int *)take((size_t)batch * 16);
+    w.nb13 = (int *)take((size_t)batch * N * 4); w.c6s = (double *)take((size_t)batch * N * 8); w.cnt = (int *)take((size_t)batch * 16);
     w.atoms = (int *)take((size_t)batch * w.cap * 16); w.fc = (double *)take((size_t)batch * w.cap * 8); w.bv = (double *)take((size_t)batch * w.cap * 96);
     w.scr = (int *)take((size_t)batch * (w.cap + 2 * N + 8) * 4);
     int rc = MOPT_OK;
     {
         mopt_scope sc(ctx, "model_hessian", 4);
-        hipLaunchKernelGGL(k_mh_connect, dim3(N, batch), dim3(128), 0, ctx->stream, N, d_X, d_par, w);
+        hipLaunchKernelGGL(k_mh_connect, dim3(N, batch), dim3(128), 0, ctx->stream, kind, N, d_X, d_par, w);
         hipLaunchKernelGGL(k_mh_enumerate, dim3(batch), dim3(256), 0, ctx->stream, N, w);
-        hipLaunchKernelGGL(k_mh_internals, dim3((w.cap + 63) / 64, batch), dim3(64), 0, ctx->stream, N, d_X, d_par, w);
+        hipLaunchKernelGGL(k_mh_internals, dim3((w.cap + 63) / 64, batch), dim3(64), 0, ctx->stream, kind, N, d_X, d_par, w);
         if ((size_t)9 * N * 8 > 48000)
             hipFuncSetAttribute((const void *)k_mh_assemble, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 8192);
-        hipLaunchKernelGGL(k_mh_assemble, dim3(N, batch), dim3(128), (size_t)9 * N * 8, ctx->stream, N, d_X, d_par, w, d3[0], d3[1], d3[2], d3[3], d_H);
+        hipLaunchKernelGGL(k_mh_assemble, dim3(N, batch), dim3(128), (size_t)9 * N * 8, ctx->stream, kind, N, d_X, d_par, w, d3[0], d3[1], d3[2], d3[3], d_H);
     }
     std::vector<int> cnt((size_t)4 * batch);
     hipError_t e = hipMemcpyAsync(cnt.data(), w.cnt, cnt.size() * 4, hipMemcpyDeviceToHost, ctx->stream);

@@ -67,7 +67,7 @@ int mopt_launch_sym_add(mopt_ctx *ctx, int n, int batch, const double *d_H, cons
 int mopt_launch_afir(mopt_ctx *ctx, int N, const double *d_x, const double *d_cov, int n1, const int *d_f1, int n2, const int *d_f2, double alpha,
                      double *d_work, double *d_E, double *d_grad, double *d_H);
 // FischerD3ApproxHessianOld.main for a batch of geometries (k_modelhess.hip); d3 is a HOST array {s6, s8, a1, a2}
-int mopt_launch_model_hessian(mopt_ctx *ctx, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
+int mopt_launch_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
                               double *d_W, double *d_A, bool project);
 int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,

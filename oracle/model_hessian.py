@@ -1,8 +1,10 @@
 """ORACLE (test infrastructure, never imported by the product): NumPy restatement of the reference's model Hessian path
   ApproxHessian.main                multioptpy/ModelHessian/approx_hessian.py:30-112  (dispatch by substring)
   FischerD3ApproxHessianOld.main    multioptpy/ModelHessian/fischerd3old.py:355-381   (the `-modelhess` default, interface.py:325-330)
+  FischerD3ApproxHessian.main       multioptpy/ModelHessian/fischerd3.py:177-304      (coordination-number scaled D3 pairs)
+  FischerApproxHessian.main         multioptpy/ModelHessian/fischer.py:216-236        (no dispersion term)
 with its helpers: BondConnectivity (Utils/bond_connectivity.py:7-135), stretch2 / bend2 / torsion2 (ModelHessian/calc_params.py:139-227).
-Pinned by tests/golden/g10_model_hessian.npz (outputs of the reference itself).  Coordinates in bohr."""
+Pinned by tests/golden/g10_model_hessian.npz and g10b_model_hessian_variants.npz (outputs of the reference itself).  Coordinates in bohr."""
 import json
 import os
 
@@ -24,7 +26,7 @@ def tables():
 
 def element_params(element_list):
     t = tables()["elements"]
-    return {k: np.array([t[e][k] for e in element_list], dtype=float) for k in ("cov", "c6", "vdw", "r4r2")}
+    return {k: np.array([t[e][k] for e in element_list], dtype=float) for k in ("cov", "c6", "vdw", "r4r2", "refcn")}
 
 
 # ---- connectivity (bond_connectivity.py:14-135) ----------------------------------------------------------------------
@@ -218,10 +220,138 @@ def fischer_d3_old(coord, element_list, project=True):
     return pj.project_hessian_trrot(H, coord) if project else H
 
 
+def _fischer_internals(H, coord, cov, C11, nbcount, variant):
+    """Bond / angle / dihedral terms of the three Fischer variants.  variant: 'd3old' (fischerd3old.py:157-325), 'd3'
+    (fischerd3.py:83-175) or 'plain' (fischer.py:75-214); they differ in the guards only."""
+    def add(atoms, b, fc):
+        for m, am in enumerate(atoms):
+            for q, aq in enumerate(atoms):
+                H[3 * am:3 * am + 3, 3 * aq:3 * aq + 3] += fc * np.outer(b[m], b[q])
+
+    for i, j in bond_table(C11):
+        r = np.linalg.norm(coord[i] - coord[j])
+        if variant == "d3" and r < 0.1:                  # fischerd3.py:88
+            continue
+        fc = 0.3601 * np.exp(-1.944 * (r - (cov[i] + cov[j])))
+        _, b = stretch2(coord[[i, j]])
+        add((i, j), b, fc)
+    angles = angle_table(C11)
+    for i, j, k in angles:
+        vij, vjk = coord[i] - coord[j], coord[k] - coord[j]
+        rij, rjk = np.linalg.norm(vij), np.linalg.norm(vjk)
+        if variant != "plain":                           # fischer.py:103-131 has no guard
+            if rij < 0.1 or rjk < 0.1:
+                continue
+            if abs(np.dot(vij, vjk) / (rij * rjk)) > 0.9999:
+                continue
+        cij, cjk = cov[i] + cov[j], cov[j] + cov[k]
+        val = cij * cjk
+        fc = 0.0 if abs(val) < 1e-10 else 0.089 + 0.11 / val ** (-0.42) * np.exp(-0.44 * (rij + rjk - cij - cjk))
+        _, b = bend2(coord[[i, j, k]])
+        add((i, j, k), b, fc)
+    for i, j, k, l in dihedral_table(C11, angles):
+        vji, vjk, vkl = coord[i] - coord[j], coord[k] - coord[j], coord[l] - coord[k]
+        rjk = np.linalg.norm(vjk)
+        cjk = cov[j] + cov[k]
+        bsum = int(nbcount[j] + nbcount[k] - 2)
+        val = rjk * cjk
+        fc = 0.0 if abs(val) < 1e-10 else 0.0015 + 14.0 * max(bsum, 0) ** 0.57 / val ** 4.0 * np.exp(-2.85 * (rjk - cjk))
+        nji, nkl = np.linalg.norm(vji), np.linalg.norm(vkl)
+        if variant == "plain":                           # fischer.py:140-170: sin^2 of the two bond angles from cross products
+            def sin2(a, b_, c):
+                v1, v2 = coord[a] - coord[b_], coord[c] - coord[b_]
+                cr = np.cross(v1, v2)
+                n1, n2 = np.dot(v1, v1), np.dot(v2, v2)
+                return 0.0 if n1 * n2 < 1e-12 else np.dot(cr, cr) / (n1 * n2)
+            if sin2(i, j, k) < 1e-3 or sin2(j, k, l) < 1e-3:
+                continue
+        else:
+            tiny = 0.1 if variant == "d3" else 1e-8      # fischerd3.py:144 / fischerd3old.py:262
+            if nji < tiny or rjk < tiny or nkl < tiny:
+                continue
+            c1 = np.dot(vji, vjk) / (nji * rjk)
+            c2 = np.dot(-vjk, vkl) / (rjk * nkl)
+            s1, s2 = 1.0 - min(c1 ** 2, 1.0), 1.0 - min(c2 ** 2, 1.0)
+            lim = 1e-3 if variant == "d3" else 1e-4      # fischerd3.py:154 / fischerd3old.py:276
+            if s1 < lim or s2 < lim:
+                continue
+            fc *= s1 * s2
+        b = torsion2(coord[[i, j, k, l]])
+        if variant == "d3" and not np.all(np.isfinite(b)):
+            continue
+        add((i, j, k, l), b, fc)
+
+
+def _d3_pairs(H, coord, par, d3, excluded, c6scale=None):
+    N = len(coord)
+    for i in range(N):
+        for j in range(i):
+            if excluded[i, j]:
+                continue
+            rv = coord[i] - coord[j]
+            r = np.linalg.norm(rv)
+            if c6scale is None and r < 0.1:              # fischerd3old.py:340
+                continue
+            if c6scale is not None and not r > 0.1:      # fischerd3.py:201
+                continue
+            ci, cj = par["c6"][i], par["c6"][j]
+            if c6scale is not None:
+                ci, cj = ci * c6scale[i], cj * c6scale[j]
+            c6 = np.sqrt(ci * cj)
+            c8 = 3.0 * c6 * np.sqrt(par["r4r2"][i] * par["r4r2"][j])
+            blk = _d3_block(rv, r, c6, c8, par["vdw"][i] + par["vdw"][j], d3)
+            H[3 * i:3 * i + 3, 3 * i:3 * i + 3] += blk
+            H[3 * j:3 * j + 3, 3 * j:3 * j + 3] += blk
+            H[3 * i:3 * i + 3, 3 * j:3 * j + 3] -= blk
+            H[3 * j:3 * j + 3, 3 * i:3 * i + 3] -= blk
+
+
+def fischer_plain(coord, element_list, project=True):
+    """FischerApproxHessian.main (fischer.py:216-236): internal-coordinate terms only; torsion bond counts from the 1.3 x table."""
+    coord = np.asarray(coord, dtype=float).reshape(-1, 3)
+    N = len(coord)
+    cov = element_params(element_list)["cov"]
+    H = np.zeros((3 * N, 3 * N))
+    C11 = connect_matrix(coord, cov, 1.1)
+    C13 = connect_matrix(coord, cov, 1.3)
+    _fischer_internals(H, coord, cov, C11, C13.sum(axis=1), "plain")
+    H = np.triu(H) + np.triu(H, 1).T                     # fischer.py:228-230: the lower triangle takes the upper one
+    return pj.project_hessian_trrot(H, coord) if project else H
+
+
+def fischer_d3(coord, element_list, project=True):
+    """FischerD3ApproxHessian.main (fischerd3.py:177-304): Fischer terms with stricter guards + D3 pairs whose C6 is scaled by the
+    fractional coordination number (fischerd3.py:46-60, 224-229); pair exclusions and torsion bond counts from the 1.1 x table."""
+    coord = np.asarray(coord, dtype=float).reshape(-1, 3)
+    N = len(coord)
+    par = element_params(element_list)
+    cov = par["cov"]
+    d3 = tables()["d3"]
+    H = np.zeros((3 * N, 3 * N))
+    C11 = connect_matrix(coord, cov, 1.1)
+    d = np.linalg.norm(coord[:, None, :] - coord[None, :, :], axis=2)
+    np.fill_diagonal(d, np.inf)
+    term = np.clip(-16.0 * ((4.0 / 3.0) * (d / (cov[:, None] + cov[None, :])) - 1.0), -100, 100)
+    cn = np.sum(1.0 / (1.0 + np.exp(term)), axis=1)
+    scale = np.clip(1.0 - 0.05 * (cn - par["refcn"]), 0.75, 1.25)
+    _fischer_internals(H, coord, cov, C11, C11.sum(axis=1), "d3")
+    _d3_pairs(H, coord, par, d3, C11, scale)
+    H = 0.5 * (H + H.T)
+    return pj.project_hessian_trrot(H, coord) if project else H
+
+
 def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
-    """ApproxHessian.main: only the Fischer + D3 (old) model is restated; its substring test precedes 'fischerd3' and 'fischer'
-    in the reference's dispatch (approx_hessian.py:41-46)."""
+    """ApproxHessian.main: the three Fischer models are restated; the reference's substring tests come in this order
+    (approx_hessian.py:35-91): gfnff, gfn0xtb, fischerd3old, fischerd3, fischerd4, schlegel*, swart*, lindh*, fischer, morse."""
     name = approx_hess_type.lower()
-    if "gfnff" in name or "gfn0xtb" in name or "fischerd3old" not in name:
+    if "gfnff" in name or "gfn0xtb" in name:
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
-    return fischer_d3_old(coord, element_list)
+    if "fischerd3old" in name:
+        return fischer_d3_old(coord, element_list)
+    if "fischerd3" in name:
+        return fischer_d3(coord, element_list)
+    if any(k in name for k in ("fischerd4", "schlegel", "swart", "lindh")):
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
+    if "fischer" in name:
+        return fischer_plain(coord, element_list)
+    raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")

@@ -344,6 +344,29 @@ def g10_model_hessian():
     np.savez_compressed(os.path.join(HERE, "g10_model_hessian.npz"), **out)
     print("G10:", len(tags), "geometries")
 
+def g10b_model_hessian_variants():
+    """G10b: the two other Fischer models behind ApproxHessian.main -- FischerD3ApproxHessian (coordination-number scaled D3 pairs,
+    fischerd3.py) and FischerApproxHessian (no dispersion term, fischer.py) -- on G10's geometries, each through the class and through
+    the dispatcher's substring test."""
+    from multioptpy.ModelHessian.fischerd3 import FischerD3ApproxHessian
+    from multioptpy.ModelHessian.fischer import FischerApproxHessian
+    from multioptpy.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(HERE, "g10_model_hessian.npz"))
+    out = {"tags": z["tags"]}
+    for tag in z["tags"]:
+        x, elems = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]]
+        g = np.zeros_like(x)
+        with quiet():
+            H3 = FischerD3ApproxHessian().main(x.copy(), list(elems), g)
+            H3d = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="fischerd3")
+            Hp = FischerApproxHessian().main(x.copy(), list(elems), g)
+            Hpd = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="fischer")
+        out[tag + "_x"], out[tag + "_elems"] = x, z[tag + "_elems"]
+        out[tag + "_Hd3"], out[tag + "_Hd3disp"], out[tag + "_Hplain"], out[tag + "_Hplaindisp"] = np.array(H3), np.array(H3d), np.array(Hp), np.array(Hpd)
+    np.savez_compressed(os.path.join(HERE, "g10b_model_hessian_variants.npz"), **out)
+    print("G10b:", len(out["tags"]), "geometries x 2 models")
+
+
 
 def g11_afir():
     """G11: AFIRPotential.calc_energy with its gradient and Hessian as the reference obtains them (torch.func.jacrev / hessian,
@@ -854,7 +877,7 @@ def g8_nebmain():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g11", "g12", "g13"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -865,6 +888,8 @@ if __name__ == "__main__":
         g3_rsprfo()
     if "g10" in which:
         g10_model_hessian()
+    if "g10b" in which:
+        g10b_model_hessian_variants()
     if "g11" in which:
         g11_afir()
     if "g12" in which:

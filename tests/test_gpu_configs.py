@@ -361,6 +361,44 @@ def test_model_hessian_fischerd3old_vs_reference():
     print("model Hessian: worst deviation from the reference", worst)
 
 
+def test_model_hessian_fischer_variants_vs_reference():
+    """G10b: the device's FischerD3 (coordination-number scaled pairs, fischerd3.py) and plain Fischer (fischer.py) model Hessians
+    against the reference's own outputs (<= 1e-8), through the plugin class; a batch of two geometries; a 100-atom argon cluster
+    (pair terms with every atom's C6 scaled) and the alkane chain against the oracle; the band entry point."""
+    import os
+    from oracle import model_hessian as mh
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    from multioptpy_amd.band import Band
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g10b_model_hessian_variants.npz"))
+    worst = 0.0
+    for t in z["tags"]:
+        el = [str(e) for e in z[t + "_elems"]]
+        for name, key in (("fischerd3", "_Hd3"), ("fischer", "_Hplain")):
+            H = ApproxHessian().main(z[t + "_x"], el, np.zeros_like(z[t + "_x"]), approx_hess_type=name)
+            err = np.abs(H - z[t + key]).max()
+            worst = max(worst, err)
+            assert err < 1e-8, (t, name, err)
+    a, b = "aldol_rxn", "aldol_jitter"
+    el = [str(e) for e in z[a + "_elems"]]
+    for name, key in (("fischerd3", "_Hd3"), ("fischer", "_Hplain")):
+        Hb = ApproxHessian().batch(np.array([z[a + "_x"], z[b + "_x"]]), el, approx_hess_type=name)
+        assert np.abs(Hb[0] - z[a + key]).max() < 1e-8 and np.abs(Hb[1] - z[b + key]).max() < 1e-8
+    x = cases.cluster(100)
+    assert np.abs(ApproxHessian().main(x, ["Ar"] * 100, None, "fischerd3") - mh.fischer_d3(x, ["Ar"] * 100)).max() < 1e-10
+    assert np.abs(ApproxHessian().main(x, ["Ar"] * 100, None, "fischer")).max() == 0.0
+    # band entry point: the resident Hessians of a 4-image band of the aldol geometry take the model
+    N = len(el)
+    X = np.array([z[a + "_x"] + 0.01 * k for k in range(4)])
+    band = Band(4, N)
+    band.upload(X, np.zeros(4), np.zeros((4, N, 3)))
+    band.model_hessian(el, "fischerd3")
+    for i in (0, 3):
+        ref = mh.fischer_d3(X[i], el)
+        assert np.abs(band.get_hessian(i) - ref).max() < 1e-9
+    band.close()
+    print("model Hessian variants: worst deviation from the reference", worst)
+
+
 def test_model_hessian_large_cluster_vs_oracle():
     """100 and 200 atoms (argon: D3 pair terms only; a C/H chain: thousands of internal coordinates) against the oracle."""
     from oracle import model_hessian as mh
@@ -383,6 +421,10 @@ def test_model_hessian_large_cluster_vs_oracle():
     ref = mh.fischer_d3_old(x, el)
     assert np.abs(ref).max() > 0.1
     assert np.abs(H - ref).max() < 1e-9, np.abs(H - ref).max()
+    for name, fn in (("fischerd3", mh.fischer_d3), ("fischer", mh.fischer_plain)):
+        H = ApproxHessian().main(x, el, None, name)
+        ref = fn(x, el)
+        assert np.abs(H - ref).max() < 1e-9, (name, np.abs(H - ref).max())
 
 
 def test_band_model_hessian_resident_and_driver():

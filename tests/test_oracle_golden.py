@@ -349,6 +349,25 @@ def test_g10_model_hessian_oracle_vs_reference():
         mh.approx_hessian(z["co2_x"], ["O", "C", "O"], None, "lindh2007d3")
 
 
+def test_g10b_model_hessian_variants_oracle_vs_reference():
+    """G10b: FischerD3ApproxHessian.main (coordination-number scaled D3) and FischerApproxHessian.main (no dispersion) of the
+    reference, through the classes and through ApproxHessian.main's substring dispatch, against the oracle's restatements; the
+    three Fischer models are told apart by the data (they differ by far more than the tolerance)."""
+    from oracle import model_hessian as mh
+    z = np.load(os.path.join(G, "g10b_model_hessian_variants.npz"))
+    zo = np.load(os.path.join(G, "g10_model_hessian.npz"))
+    for t in z["tags"]:
+        el = [str(e) for e in z[t + "_elems"]]
+        H3 = mh.approx_hessian(z[t + "_x"], el, None, "fischerd3")
+        Hp = mh.approx_hessian(z[t + "_x"], el, None, "fischer")
+        assert np.abs(H3 - z[t + "_Hd3"]).max() < 1e-13, t
+        assert np.abs(Hp - z[t + "_Hplain"]).max() < 1e-13, t
+        assert np.array_equal(z[t + "_Hd3"], z[t + "_Hd3disp"]) and np.array_equal(z[t + "_Hplain"], z[t + "_Hplaindisp"]), t
+    for t in ("aldol_rxn", "claisen_rearrengment", "ar13"):
+        assert np.abs(z[t + "_Hd3"] - zo[t + "_H"]).max() > 1e-5, t
+        assert np.abs(z[t + "_Hplain"] - zo[t + "_H"]).max() > 1e-5, t
+
+
 def test_g11_afir_oracle_vs_reference():
     """G11: AFIR energy, gradient and Hessian (the reference's torch autograd outputs) against the oracle's analytic form."""
     from oracle import afir, model_hessian as mh
