@@ -2490,7 +2490,10 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         } else MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side2));
     }
     // divide and conquer (k_dc.hip) for matrices with an unreduced block of more than dc_min rows; MOPT_TRI_DC=0 switches it off
-    const int dc_min = (tri_env("MOPT_TRI_DC") && atoi(tri_env("MOPT_TRI_DC")) == 0) ? 0 : (tri_env("MOPT_TRI_DCMIN") ? atoi(tri_env("MOPT_TRI_DCMIN")) : TRI_SMALL);
+    // (default 32 since the end of round 2: a 33..64-row block costs the two-wave Jacobi k_tri_small<64,33> 0.37 ms (33 rows) to 0.8 ms
+    // (50 rows) against ~0.15 ms for the chain -- single 33 x 33 Hessian 0.74 -> 0.53 ms per RSIRFO.run, 60-step average of the headline
+    // band 1.31 -> 1.12 ms; MOPT_TRI_DCMIN=64 restores the old split and keeps the Jacobi instantiation under test)
+    const int dc_min = (tri_env("MOPT_TRI_DC") && atoi(tri_env("MOPT_TRI_DC")) == 0) ? 0 : (tri_env("MOPT_TRI_DCMIN") ? atoi(tri_env("MOPT_TRI_DCMIN")) : 32);
     int *d_dcflag = nullptr;
     if (dc_min > 0 && n > dc_min) {
         const size_t need = 256 + mopt_dc_scratch_bytes(n, batch) + (size_t)batch * 4;

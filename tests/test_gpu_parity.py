@@ -341,7 +341,7 @@ def test_rsprfo_traces_vs_reference():
 
 @pytest.mark.parametrize("algo", ["tridiag", "jacobi", "tridiag-stepwise", "tridiag-persistent", "tridiag-nosmall", "tridiag-persist2",
                                   "tridiag-valubacktrans", "tridiag-group8", "tridiag-small32", "tridiag-notail", "tridiag-tail192",
-                                  "tridiag-tail100w16", "tridiag-jacobismall"])
+                                  "tridiag-tail100w16", "tridiag-jacobismall", "tridiag-dcmin64"])
 def test_eigh_forced_route(ops, algo):
     """Both eigen-solvers forced for every size (MOPT_EIGH_ALGO): random, degenerate, clustered and LJ matrices.
     (By default the reduction route runs from n = 32 on and the Jacobi sweeps below.)"""
@@ -396,7 +396,9 @@ sys.exit(bad)
              # the persistent kernel for n = 300 (8- and 16-wave forms of the three-chunk kernel)
              "tridiag-tail192": {"MOPT_TRI_TAILONLY": "192", "MOPT_TRI_TAILMAX": "192"},
              "tridiag-tail100w16": {"MOPT_TRI_TAILONLY": "192", "MOPT_TRI_TAILMAX": "100", "MOPT_TAIL_W8": "0"},
-             "tridiag-jacobismall": {"MOPT_TRI_QL": "0"}}.get(algo, {})
+             "tridiag-jacobismall": {"MOPT_TRI_QL": "0"},
+             # blocks of 33..64 rows by the two-wave Jacobi (the default until the end of round 2; now they go to divide and conquer)
+             "tridiag-dcmin64": {"MOPT_TRI_DCMIN": "64"}}.get(algo, {})
     env = dict(os.environ, MOPT_EIGH_ALGO=algo.split("-")[0], **extra)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(__file__)))
     print(r.stdout)
