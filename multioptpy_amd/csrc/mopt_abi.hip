@@ -1,5 +1,8 @@
 // C ABI of libmopt_hip.so (see include/mopt_hip.h): context, workspaces and the host-pointer entry points.
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
 #include <new>
 
 #include "common.hpp"
@@ -63,6 +66,31 @@ extern "C" int mopt_ctx_create(int device, mopt_ctx **out) {
     return MOPT_OK;
 }
 
+// Pinned host staging per context (grow-only; freed by mopt_ctx_destroy): the small inputs / outputs of the single-geometry entry
+// points travel through it in one copy per direction.
+namespace {
+struct PinBuf { void *p = nullptr; size_t bytes = 0; };
+std::map<mopt_ctx *, PinBuf> g_pin;
+std::mutex g_pin_mu;
+void *pin_get(mopt_ctx *ctx, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    PinBuf &b = g_pin[ctx];
+    if (b.bytes < bytes) {
+        if (b.p) hipHostFree(b.p);
+        b.p = nullptr; b.bytes = 0;
+        const size_t want = bytes < (1u << 16) ? (1u << 16) : bytes;
+        if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { b.p = nullptr; return nullptr; }
+        b.bytes = want;
+    }
+    return b.p;
+}
+void pin_release(mopt_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    auto it = g_pin.find(ctx);
+    if (it != g_pin.end()) { if (it->second.p) hipHostFree(it->second.p); g_pin.erase(it); }
+}
+}  // namespace
+
 extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     if (!ctx) return MOPT_E_ARG;
     hipSetDevice(ctx->device);
@@ -78,6 +106,7 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipEventDestroy(ctx->ev_fork5); hipEventDestroy(ctx->ev_join5);
     hipEventDestroy(ctx->ev_fork6); hipEventDestroy(ctx->ev_join6);
     if (ctx->early_buf) hipFree(ctx->early_buf);
+    pin_release(ctx);
     hipStreamDestroy(ctx->side3);
     hipStreamDestroy(ctx->side2);
     hipStreamDestroy(ctx->side);
@@ -424,15 +453,7 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
     RsirfoWork wk;
     TRY(wk.alloc(ctx, n, batch, /*own_hessian=*/true, bias_hessian != nullptr, H_inplace != nullptr));
     const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
-    H2D(ctx, wk.H, hessian, nn);
-    if (bias_hessian) H2D(ctx, wk.Bias, bias_hessian, nn);
-    H2D(ctx, wk.x, geom, nv); H2D(ctx, wk.bg, B_g, nv);
-    H2D(ctx, wk.g, g ? g : B_g, nv);
     const bool have_prev = pre_geom && pre_g;
-    if (have_prev) { H2D(ctx, wk.px, pre_geom, nv); H2D(ctx, wk.pg, pre_g, nv); }
-    H2D(ctx, wk.be, B_e, batch * sizeof(double));
-    H2D(ctx, wk.params, params, batch * sizeof(mopt_rsirfo_params));
-    H2D(ctx, wk.states, state, batch * sizeof(mopt_rsirfo_state));
     std::vector<int> rules(batch), upd(batch);
     bool any_flow = false, any_upd = false;
     for (int b = 0; b < batch; ++b) {
@@ -442,14 +463,52 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
         any_flow |= (rules[b] == MOPT_RULE_FLOWCHART);
         any_upd |= upd[b] != 0;
     }
-    H2D(ctx, wk.rules, rules.data(), batch * sizeof(int));
-    H2D(ctx, wk.do_update, upd.data(), batch * sizeof(int));
+    // The small inputs travel as ONE copy from a pinned staging buffer into one device span, the outputs [states | step] and -- up to
+    // 1 MB each -- the Hessians come back through it as well, so no copy of the call blocks on pageable memory before the final
+    // synchronisation (twelve small pageable copies in and four out were 130 us of a 0.5 ms call).  The span replaces the workspace's
+    // own arrays of the same names for this call (the workspace layout itself is shared with the band and stays as it is):
+    //   in:  [x | bg | g | px | pg | be | params | rules | do_update | states]      out: [states | step]
+    DBuf io;
+    {
+        auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+        const size_t tot = 6 * al(nv) + al(batch * sizeof(double)) + al(batch * sizeof(mopt_rsirfo_params)) + 2 * al(batch * sizeof(int)) +
+                           al(batch * sizeof(mopt_rsirfo_state));
+        TRY(io.alloc(ctx, tot));
+        char *q = (char *)io.p;
+        auto take = [&](size_t bytes) { void *r = q; q += al(bytes); return r; };
+        wk.x = (double *)take(nv); wk.bg = (double *)take(nv); wk.g = (double *)take(nv); wk.px = (double *)take(nv); wk.pg = (double *)take(nv);
+        wk.be = (double *)take(batch * sizeof(double));
+        wk.params = (mopt_rsirfo_params *)take(batch * sizeof(mopt_rsirfo_params));
+        wk.rules = (int *)take(batch * sizeof(int)); wk.do_update = (int *)take(batch * sizeof(int));
+        wk.states = (mopt_rsirfo_state *)take(batch * sizeof(mopt_rsirfo_state));
+        wk.step = (double *)take(nv);
+    }
+    const size_t in_bytes = (size_t)((char *)wk.step - (char *)wk.x), out_bytes = (size_t)((char *)wk.step - (char *)wk.states) + nv;
+    const bool stage_H = nn <= ((size_t)1 << 20);
+    const size_t hs_off = (in_bytes + out_bytes + 255) & ~(size_t)255, hi_off = hs_off + (stage_H ? ((nn + 255) & ~(size_t)255) : 0);
+    char *pin = (char *)pin_get(ctx, hi_off + (stage_H ? nn : 0));
+    if (!pin) { ctx->err = "hipHostMalloc failed (staging buffer)"; return MOPT_E_NOMEM; }
+    auto put = [&](const void *dev_field, const void *src, size_t bytes) { std::memcpy(pin + ((const char *)dev_field - (const char *)wk.x), src, bytes); };
+    put(wk.x, geom, nv); put(wk.bg, B_g, nv); put(wk.g, g ? g : B_g, nv);
+    if (have_prev) { put(wk.px, pre_geom, nv); put(wk.pg, pre_g, nv); }
+    put(wk.be, B_e, batch * sizeof(double));
+    put(wk.params, params, batch * sizeof(mopt_rsirfo_params));
+    put(wk.states, state, batch * sizeof(mopt_rsirfo_state));
+    put(wk.rules, rules.data(), batch * sizeof(int));
+    put(wk.do_update, upd.data(), batch * sizeof(int));
+    H2D(ctx, wk.x, pin, in_bytes);
+    H2D(ctx, wk.H, hessian, nn);
+    if (bias_hessian) H2D(ctx, wk.Bias, bias_hessian, nn);
     TRY(mopt_rsirfo_pipeline(ctx, wk, n, batch, any_upd, any_flow, wk.Hinpl, wk.H /* symmetrised in place */));
-    D2H(ctx, step, wk.step, nv);
-    D2H(ctx, state, wk.states, batch * sizeof(mopt_rsirfo_state));
-    if (H_sym) D2H(ctx, H_sym, wk.H, nn);
-    if (H_inplace) D2H(ctx, H_inplace, any_upd ? wk.Hinpl : wk.H, nn);
+    char *pout = pin + in_bytes;
+    D2H(ctx, pout, wk.states, out_bytes);
+    if (H_sym) D2H(ctx, stage_H ? (void *)(pin + hs_off) : (void *)H_sym, wk.H, nn);
+    if (H_inplace) D2H(ctx, stage_H ? (void *)(pin + hi_off) : (void *)H_inplace, any_upd ? wk.Hinpl : wk.H, nn);
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(state, pout, batch * sizeof(mopt_rsirfo_state));
+    std::memcpy(step, pout + ((char *)wk.step - (char *)wk.states), nv);
+    if (stage_H && H_sym) std::memcpy(H_sym, pin + hs_off, nn);
+    if (stage_H && H_inplace) std::memcpy(H_inplace, pin + hi_off, nn);
     for (int b = 0; b < batch; ++b)
         if (state[b].jacobi_sweeps < 0) { ctx->err = "mopt_rsirfo_run: the eigen-solver failed"; return MOPT_E_NUMERIC; }
     return MOPT_OK;

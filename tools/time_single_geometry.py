@@ -13,7 +13,8 @@ import cases  # noqa: E402
 from multioptpy_amd.Optimizer.rsirfo import RSIRFO  # noqa: E402
 from multioptpy_amd.Optimizer.rsprfo import EnhancedRSPRFO  # noqa: E402
 
-for N in (7, 11, 22, 100, 200):
+SIZES = tuple(int(a) for a in sys.argv[1:]) or (7, 11, 22, 100, 200)
+for N in SIZES:
     n = 3 * N
     x = cases.cluster(N, jitter=0.3) * 0.95
     for cls, method, order in ((RSIRFO, "rsirfo_bfgs", 0), (EnhancedRSPRFO, "rsprfo_bofill", 1)):
