@@ -72,7 +72,7 @@ namespace {
 struct PinBuf { void *p = nullptr; size_t bytes = 0; };
 std::map<mopt_ctx *, PinBuf> g_pin;
 std::mutex g_pin_mu;
-void *pin_get(mopt_ctx *ctx, size_t bytes) {
+void *pin_get_impl(mopt_ctx *ctx, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     PinBuf &b = g_pin[ctx];
     if (b.bytes < bytes) {
@@ -84,12 +84,17 @@ void *pin_get(mopt_ctx *ctx, size_t bytes) {
     }
     return b.p;
 }
+void *pin_get(mopt_ctx *ctx, size_t bytes) { return pin_get_impl(ctx, bytes); }
 void pin_release(mopt_ctx *ctx) {
     std::lock_guard<std::mutex> lk(g_pin_mu);
     auto it = g_pin.find(ctx);
     if (it != g_pin.end()) { if (it->second.p) hipHostFree(it->second.p); g_pin.erase(it); }
 }
 }  // namespace
+
+// (for the other host entry points of the library: k_prfo.hip)
+void *mopt_pin_get(mopt_ctx *ctx, size_t bytes) { return pin_get_impl(ctx, bytes); }
+
 
 extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     if (!ctx) return MOPT_E_ARG;
