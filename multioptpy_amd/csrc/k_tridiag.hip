@@ -2244,7 +2244,8 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     // (n = 42: 0.053 against 0.065 ms; n = 96: 0.153 against 0.141 ms; MOPT_TRI_TAILONLY=<n> moves the limit).  As the tail of a
     // larger matrix (k_tri_persist3 stopped early, MOPT_TRI_TAILMAX=<rows>) it pays only where a persistent step is expensive: the
     // 8-wave groups of n > 384 (3.0 us per step; n = 600: 3.91 -> 3.56 ms with a 128-row tail), not at n = 300 (0.61 ms either way).
-    const bool use_tail = multi && !(tri_env("MOPT_TRI_TAIL") && atoi(tri_env("MOPT_TRI_TAIL")) == 0);
+    // (also below n = 32, where the alternative is the one-workgroup k_tridiag: n = 21 0.075 -> 0.03 ms)
+    const bool use_tail = (multi || (n >= 16 && !tri_env("MOPT_TRI_SINGLE"))) && !(tri_env("MOPT_TRI_TAIL") && atoi(tri_env("MOPT_TRI_TAIL")) == 0);
     const int tail_only = tri_env("MOPT_TRI_TAILONLY") ? std::min(atoi(tri_env("MOPT_TRI_TAILONLY")), mopt_tri_tail_max()) : 80;
     const int tail_max = tri_env("MOPT_TRI_TAILMAX") ? std::min(atoi(tri_env("MOPT_TRI_TAILMAX")), mopt_tri_tail_max()) : (tr8 > 0 ? 128 : 0);
     if (use_tail && n <= tail_only && !tri_env("MOPT_TRI_FORCEPERSIST")) {

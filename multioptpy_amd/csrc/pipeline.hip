@@ -134,5 +134,8 @@ int mopt_eigh_algo(int n) {
         algo = !e ? -1 : (e[0] == 't' || e[0] == '1') ? 1 : 0;
     }
     if (n < 3) return 0;
-    return algo >= 0 ? algo : (n >= 32 ? 1 : 0);
+    // smallest n of the reduction route: 16 since the end of round 2 (single-compute-unit tridiagonalisation + one-wave QL: n = 21
+    // 0.48 -> 0.38 ms per RSIRFO.run, n = 27 0.56 -> 0.46 against the block Jacobi's 7 sweeps of 40 us; MOPT_EIGH_MIN=32 restores)
+    static const int nmin = getenv("MOPT_EIGH_MIN") ? atoi(getenv("MOPT_EIGH_MIN")) : 16;
+    return algo >= 0 ? algo : (n >= nmin ? 1 : 0);
 }
