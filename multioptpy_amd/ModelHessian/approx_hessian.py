@@ -3,8 +3,8 @@
 ``main(coord, element_list, cart_gradient, approx_hess_type)`` keeps the reference's signature (coord in bohr) and its dispatch by
 substring.  On the device (``mopt_model_hessian`` of include/mopt_hip.h): the Fischer + D3 model the reference's ``-modelhess``
 switch selects by default (``fischerd3old``, interface.py:325-330; ModelHessian/fischerd3old.py:355-381), the Fischer model with
-coordination-number scaled D3 pairs (``fischerd3``, ModelHessian/fischerd3.py:177-304) and the plain Fischer model (``fischer``,
-ModelHessian/fischer.py:216-236).  Other model names raise NotImplementedError; there is no CPU fallback.
+coordination-number scaled D3 pairs (``fischerd3``, ModelHessian/fischerd3.py:177-304), the plain Fischer model (``fischer``,
+ModelHessian/fischer.py:216-236) and Schlegel's model (``schlegel``, ModelHessian/schlegel.py:66-144).  Other model names raise NotImplementedError; there is no CPU fallback.
 
 Per-element parameters (covalent radii, C6, van-der-Waals radii, r4/r2, D3 scaling) are the numbers the reference's
 ``multioptpy/Parameters`` functions return, kept as data in ``element_tables.json`` (tools/extract_element_tables.py)."""
@@ -17,7 +17,7 @@ import numpy as np
 from .. import _lib
 from .._lib import lib, check, f64, ptr
 
-MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER = 0, 1, 2
+MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER, MODEL_SCHLEGEL = 0, 1, 2, 3
 _TAB = None
 
 
@@ -29,12 +29,22 @@ def _tables():
     return _TAB
 
 
+def _schlegel_code(e, order):
+    """Row of Schlegel's B table for an element as the reference assigns it (schlegel.py:27-63: H-He, Li-Ne, K-Kr, Rb-Xe, Cs-Rn,
+    everything else -- Na-Ar included -- in the last row), + 8 for hydrogen (its angle constant, schlegel.py:101-106)."""
+    z = order.index(e) + 1 if e in order else 999
+    row = 0 if z <= 2 else 1 if z <= 10 else 2 if 19 <= z <= 36 else 3 if 37 <= z <= 54 else 4 if 55 <= z <= 86 else 5
+    return row + (8 if e == "H" else 0)
+
+
 def element_parameters(element_list):
-    """(par, d3): par = [cov | c6 | vdw | r4r2 | refcn] as one (5 N,) array, d3 = (s6, s8, a1, a2) -- the arguments of the C ABI."""
+    """(par, d3): par = [cov | c6 | vdw | r4r2 | refcn | schlegel code] as one (6 N,) array, d3 = (s6, s8, a1, a2) -- the arguments
+    of the C ABI."""
     t = _tables()
     el = t["elements"]
     try:
-        par = np.concatenate([np.array([el[str(e)][k] for e in element_list], dtype=np.float64) for k in ("cov", "c6", "vdw", "r4r2", "refcn")])
+        par = np.concatenate([np.array([el[str(e)][k] for e in element_list], dtype=np.float64) for k in ("cov", "c6", "vdw", "r4r2", "refcn")]
+                             + [np.array([_schlegel_code(str(e), t["order"]) for e in element_list], dtype=np.float64)])
     except KeyError as e:
         raise KeyError(f"no model-Hessian parameters for element {e}") from None
     d3 = np.array([t["d3"][k] for k in ("s6", "s8", "a1", "a2")], dtype=np.float64)
@@ -53,10 +63,14 @@ def model_kind(approx_hess_type):
         kind, base = MODEL_FISCHERD3OLD, "fischerd3old"
     elif "fischerd3" in name:
         kind, base = MODEL_FISCHERD3, "fischerd3"
-    elif not any(k in name for k in ("fischerd4", "schlegel", "swart", "lindh")) and "fischer" in name:
+    elif "fischerd4" in name or "schlegeld3" in name or "schlegeld4" in name:
+        pass
+    elif "schlegel" in name:
+        kind, base = MODEL_SCHLEGEL, "schlegel"
+    elif not any(k in name for k in ("swart", "lindh")) and "fischer" in name:
         kind, base = MODEL_FISCHER, "fischer"
     if kind is None:
-        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, fischer)")
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, fischer, schlegel)")
     for suffix in ("ts", "sr", "clip"):                  # approx_hessian.py:93-110: modifiers applied after the model
         if suffix in name.replace(base, ""):
             raise NotImplementedError(f"model Hessian modifier '{suffix}' is not available on the device")

@@ -534,12 +534,12 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
 extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par, const double *d3) {
     if (!b || !par || !d3) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
-    if (kind != MOPT_MODEL_FISCHERD3OLD && kind != MOPT_MODEL_FISCHERD3 && kind != MOPT_MODEL_FISCHER) { ctx->err = "mopt_band_model_hessian: unknown model"; return MOPT_E_ARG; }
+    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_SCHLEGEL) { ctx->err = "mopt_band_model_hessian: unknown model"; return MOPT_E_ARG; }
     if (!b->uploaded) { ctx->err = "mopt_band_model_hessian: no geometries uploaded"; return MOPT_E_STATE; }
     hipSetDevice(ctx->device);
     double *d_par = nullptr;
-    MOPT_HIP_TRY(ctx, hipMalloc((void **)&d_par, (size_t)5 * b->N * 8));
-    hipError_t e = hipMemcpyAsync(d_par, par, (size_t)5 * b->N * 8, hipMemcpyHostToDevice, ctx->stream);
+    MOPT_HIP_TRY(ctx, hipMalloc((void **)&d_par, (size_t)6 * b->N * 8));
+    hipError_t e = hipMemcpyAsync(d_par, par, (size_t)6 * b->N * 8, hipMemcpyHostToDevice, ctx->stream);
     int rc = (e == hipSuccess) ? mopt_launch_model_hessian(ctx, kind, b->N, b->count, b->X + (size_t)b->first * b->n, d_par, d3, b->wk.Gt, b->wk.Q, b->wk.W6, b->wk.H, true)
                                : MOPT_E_DEVICE;
     // the projection's rank-12 correction is symmetric only up to rounding (a q w + w q pair is folded into an FMA): one in-place

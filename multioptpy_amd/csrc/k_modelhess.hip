@@ -7,6 +7,10 @@
 //                         number (fischerd3.py:46-60, 224-229; k_mh_connect), stricter guards (fischerd3.py:88, 144-155)
 //   MOPT_MODEL_FISCHER    FischerApproxHessian.main (fischer.py:216-236): no pair term, no angle guard, cross-product linearity test
 //                         of the torsions (fischer.py:140-170), no sin^2 damping
+//   MOPT_MODEL_SCHLEGEL   SchlegelApproxHessian.main (schlegel.py:66-144): H = B^T K B over the all-pairs stretch rows of
+//                         redundant_coordinate.py:15-43 with a diagonal K filled from the three tables -- every contribution lands on a
+//                         bonded pair, so the model is "one spring per bond": the bond lane of k_mh_internals walks the angle and
+//                         dihedral tables in the reference's order (same sum, bit for bit) and k_mh_assemble adds k u u^T blocks
 //   k_mh_connect     distance tests -> two connectivity tables: 1.1 x covalent radii (BondConnectivity, Utils/bond_connectivity.py:
 //                    14-41: the internal coordinates) and 1.3 x (fischerd3old.py:136-154: torsion bond counts, D3 exclusions)
 //   k_mh_enumerate   bond / angle / dihedral tables in the reference's order (bond_connectivity.py:43-128; the dihedral rules depend
@@ -161,6 +165,13 @@ __global__ void __launch_bounds__(256) k_mh_enumerate(int N, MhWork w) {
     if (tid == 0) { cnt[0] = ovb ? 0 : nb; cnt[1] = ova ? 0 : na; cnt[2] = nd; cnt[3] = (ova || abase + na + nd > w.cap) ? 1 : 0; if (cnt[3]) cnt[2] = 0; }
 }
 
+// Schlegel's B parameters (bohr) by row of the periodic table as schlegel.py:27-63 assigns them (its K-Kr / Rb-Xe / Cs-Rn lists leave
+// Na-Ar in the last row: reproduced through the per-atom code the host passes, par[5 N + i] = row + 8 * (element is H))
+__constant__ double c_schlegel_b[7][7] = {{0.2573, 0.3401, 0.6937, 0.7126, 0.8335, 0.9491, 0.9491}, {0.3401, 0.9652, 1.2843, 1.4725, 1.6549, 1.7190, 1.7190},
+                                          {0.6937, 1.2843, 1.6925, 1.8238, 2.1164, 2.3185, 2.3185}, {0.7126, 1.4725, 1.8238, 2.0203, 2.2137, 2.5206, 2.5206},
+                                          {0.8335, 1.6549, 2.1164, 2.2137, 2.3718, 2.5110, 2.5110}, {0.9491, 1.7190, 2.3185, 2.5206, 2.5110, 2.5110, 2.5110},
+                                          {0.9491, 1.7190, 2.3185, 2.5206, 2.5110, 2.5110, 2.5110}};
+
 struct V3 { double x, y, z; };
 __device__ inline V3 sub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ inline double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -204,7 +215,36 @@ __global__ void __launch_bounds__(64) k_mh_internals(int kind, int N, const doub
     double *bv = w.bv + ((size_t)b * w.cap + e) * 12;
     double fc = 0.0;
     V3 bq[4] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    if (e < nb) {
+    if (kind == MOPT_MODEL_SCHLEGEL) {
+        if (e < nb) {
+            // the spring of bond (i, j): schlegel.py:82-91 (bond), :93-106 (0.160 / 0.250 per angle that contains the bond), :108-121
+            // (0.0023 - 0.07 (r_jk - cov_jk) per dihedral, on each of its three bonds), summed in table order
+            const int i = at[0], j = at[1];
+            const double *sch = par + 5 * (size_t)N;
+            const double r = stretch2(ld3(x, i), ld3(x, j), bq[0], bq[1]);
+            const double cb = c_schlegel_b[(int)sch[i] & 7][(int)sch[j] & 7], dd = r - cb;
+            double k = 1.734 / (dd * dd * dd);
+            const int *tab = w.atoms + (size_t)b * w.cap * 4;
+            auto same = [&](int p, int q) { return (p == i && q == j) || (p == j && q == i); };
+            for (int a = nb; a < nb + na; ++a) {
+                const int a0 = tab[4 * a], a1 = tab[4 * a + 1], a2 = tab[4 * a + 2];
+                const double v = (((int)sch[a0] & 8) || ((int)sch[a2] & 8)) ? 0.160 : 0.250;
+                if (same(a0, a1)) k += v;
+                if (same(a1, a2)) k += v;
+            }
+            for (int a = nb + na; a < nb + na + nd; ++a) {
+                const int q0 = tab[4 * a], q1 = tab[4 * a + 1], q2 = tab[4 * a + 2], q3 = tab[4 * a + 3];
+                const bool h0 = same(q0, q1), h1 = same(q1, q2), h2 = same(q2, q3);
+                if (h0 || h1 || h2) {
+                    const double v = 0.0023 - 1 * 0.07 * (norm(sub(ld3(x, q1), ld3(x, q2))) - (cov[q1] + cov[q2]));
+                    if (h0) k += v;
+                    if (h1) k += v;
+                    if (h2) k += v;
+                }
+            }
+            fc = k;
+        }
+    } else if (e < nb) {
         const int i = at[0], j = at[1];
         const double r = stretch2(ld3(x, i), ld3(x, j), bq[0], bq[1]);
         fc = (kind == MOPT_MODEL_FISCHERD3 && r < 0.1) ? 0.0 : 0.3601 * exp(-1.944 * (r - (cov[i] + cov[j])));      // (fischerd3.py:88)
@@ -318,7 +358,7 @@ __global__ void __launch_bounds__(128) k_mh_assemble(int kind, int N, const doub
     const unsigned char *c13 = ((kind == MOPT_MODEL_FISCHERD3) ? w.c11 : w.c13) + ((size_t)b * N + m) * N;
     const double *c6s = w.c6s + (size_t)b * N;
     const V3 xm = ld3(x, m);
-    for (int j = tid; j < ((kind == MOPT_MODEL_FISCHER) ? 0 : N); j += nt) {
+    for (int j = tid; j < ((kind == MOPT_MODEL_FISCHER || kind == MOPT_MODEL_SCHLEGEL) ? 0 : N); j += nt) {
         if (j == m || c13[j]) continue;
         const V3 rv = sub(xm, ld3(x, j));
         const double r = norm(rv);
@@ -359,7 +399,7 @@ __global__ void __launch_bounds__(128) k_mh_assemble(int kind, int N, const doub
 
 }  // namespace mopt
 
-// kind: MOPT_MODEL_*.  d_X: [batch][N][3] bohr; d_par: cov[N], c6[N], vdw[N], r4r2[N], refcn[N] (atomic units); d3: s6, s8, a1, a2.  Result: d_A = the projected model Hessian
+// kind: MOPT_MODEL_*.  d_X: [batch][N][3] bohr; d_par: cov[N], c6[N], vdw[N], r4r2[N], refcn[N], schlegel code[N]; d3: s6, s8, a1, a2.  Result: d_A = the projected model Hessian
 // (d_H holds the unprojected, unsymmetrised assembly).  d_Q, d_W: 6 n doubles per image.  Returns MOPT_E_ARG when an image has more
 // internal coordinates than the tables hold.
 int mopt_launch_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,

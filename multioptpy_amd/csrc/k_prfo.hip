@@ -424,13 +424,14 @@ extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *p
         PD2H(pin + o_st, dst.p, sizeof(st));
         PD2H(pin + o_row, dtsrow.p, sizeof(int));
         PD2H(pin + o_bad, wk.einfo + 1, sizeof(int));
-        PD2H(stage_H ? (void *)(pin + o_H) : (void *)H_out, wk.H, nn);
+        if (updated) PD2H(stage_H ? (void *)(pin + o_H) : (void *)H_out, wk.H, nn);
         MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(step, pin, nv);
         std::memcpy((void *)&st, pin + o_st, sizeof(st));
         std::memcpy(&ts_row, pin + o_row, sizeof(int));
         std::memcpy(&bad, pin + o_bad, sizeof(int));
-        if (stage_H) std::memcpy(H_out, pin + o_H, nn);
+        if (stage_H && updated) std::memcpy(H_out, pin + o_H, nn);
+        if (!updated && H_out != hessian) std::memcpy(H_out, hessian, nn);      // (no update: the device copy is the caller's matrix bit for bit)
     }
     if (ts_vec_out && ts_row >= 0) {
         if (bad & 1) { std::memset(ts_vec_out, 0, nv); ts_vec_out[ts_row] = 1.0; }

@@ -314,14 +314,14 @@ extern "C" int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *co
 
 extern "C" int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H) {
     if (!ctx) return MOPT_E_ARG;
-    if (kind != MOPT_MODEL_FISCHERD3OLD && kind != MOPT_MODEL_FISCHERD3 && kind != MOPT_MODEL_FISCHER) { ctx->err = "mopt_model_hessian: unknown model"; return MOPT_E_ARG; }
+    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_SCHLEGEL) { ctx->err = "mopt_model_hessian: unknown model"; return MOPT_E_ARG; }
     if (bad_dims(ctx, 3 * N, batch) || N < 1 || !X || !par || !d3 || !H) return MOPT_E_ARG;
     hipSetDevice(ctx->device);
     const int n = 3 * N;
     const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
     DBuf dH, dA, dX, dQ, dW, dP;
-    TRY(dH.alloc(ctx, nn)); TRY(dA.alloc(ctx, nn)); TRY(dX.alloc(ctx, nv)); TRY(dQ.alloc(ctx, 6 * nv)); TRY(dW.alloc(ctx, 6 * nv)); TRY(dP.alloc(ctx, (size_t)5 * N * 8));
-    H2D(ctx, dX.p, X, nv); H2D(ctx, dP.p, par, (size_t)5 * N * 8);
+    TRY(dH.alloc(ctx, nn)); TRY(dA.alloc(ctx, nn)); TRY(dX.alloc(ctx, nv)); TRY(dQ.alloc(ctx, 6 * nv)); TRY(dW.alloc(ctx, 6 * nv)); TRY(dP.alloc(ctx, (size_t)6 * N * 8));
+    H2D(ctx, dX.p, X, nv); H2D(ctx, dP.p, par, (size_t)6 * N * 8);
     TRY(mopt_launch_model_hessian(ctx, kind, N, batch, dX.as<double>(), dP.as<double>(), d3, dH.as<double>(), dQ.as<double>(), dW.as<double>(), dA.as<double>(), project != 0));
     D2H(ctx, H, dA.p, nn);
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

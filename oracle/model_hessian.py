@@ -3,6 +3,7 @@
   FischerD3ApproxHessianOld.main    multioptpy/ModelHessian/fischerd3old.py:355-381   (the `-modelhess` default, interface.py:325-330)
   FischerD3ApproxHessian.main       multioptpy/ModelHessian/fischerd3.py:177-304      (coordination-number scaled D3 pairs)
   FischerApproxHessian.main         multioptpy/ModelHessian/fischer.py:216-236        (no dispersion term)
+  SchlegelApproxHessian.main        multioptpy/ModelHessian/schlegel.py:66-144        (pair springs from the connectivity tables)
 with its helpers: BondConnectivity (Utils/bond_connectivity.py:7-135), stretch2 / bend2 / torsion2 (ModelHessian/calc_params.py:139-227).
 Pinned by tests/golden/g10_model_hessian.npz and g10b_model_hessian_variants.npz (outputs of the reference itself).  Coordinates in bohr."""
 import json
@@ -340,6 +341,69 @@ def fischer_d3(coord, element_list, project=True):
     return pj.project_hessian_trrot(H, coord) if project else H
 
 
+_SCHLEGEL_B = [[0.2573, 0.3401, 0.6937, 0.7126, 0.8335, 0.9491, 0.9491],
+               [0.3401, 0.9652, 1.2843, 1.4725, 1.6549, 1.7190, 1.7190],
+               [0.6937, 1.2843, 1.6925, 1.8238, 2.1164, 2.3185, 2.3185],
+               [0.7126, 1.4725, 1.8238, 2.0203, 2.2137, 2.5206, 2.5206],
+               [0.8335, 1.6549, 2.1164, 2.2137, 2.3718, 2.5110, 2.5110],
+               [0.9491, 1.7190, 2.3185, 2.5206, 2.5110, 2.5110, 2.5110],
+               [0.9491, 1.7190, 2.3185, 2.5206, 2.5110, 2.5110, 2.5110]]      # Schlegel 1984, bohr
+
+
+def schlegel_row(e):
+    """schlegel.py:27-63: the row of the B table an element takes.  As written there, the lists called third / fourth / fifth period
+    hold K-Kr / Rb-Xe / Cs-Rn, so Na-Ar (and everything beyond Rn) fall through to the last index."""
+    if e in ("H", "He"):
+        return 0
+    if e in ("Li", "Be", "B", "C", "N", "O", "F", "Ne"):
+        return 1
+    order = tables()["order"]
+    z = order.index(e) + 1 if e in order else 999
+    if 19 <= z <= 36:
+        return 2
+    if 37 <= z <= 54:
+        return 3
+    if 55 <= z <= 86:
+        return 4
+    return 5
+
+
+def schlegel(coord, element_list, project=True):
+    """SchlegelApproxHessian.main (schlegel.py:66-144): a diagonal force-constant matrix over ALL atom pairs (the rows of
+    RedundantInternalCoordinates.B_matrix, redundant_coordinate.py:15-43), filled from the bond / angle / dihedral tables -- every
+    entry lands on a bonded pair -- and H = B^T K B."""
+    coord = np.asarray(coord, dtype=float).reshape(-1, 3)
+    N = len(coord)
+    cov = element_params(element_list)["cov"]
+    C11 = connect_matrix(coord, cov, 1.1)
+    K = {}
+
+    def add(a, b, v):
+        key = (min(a, b), max(a, b))
+        K[key] = K.get(key, 0.0) + v
+
+    for i, j in bond_table(C11):
+        d = np.linalg.norm(coord[i] - coord[j])
+        add(i, j, 1.734 / (d - _SCHLEGEL_B[schlegel_row(element_list[i])][schlegel_row(element_list[j])]) ** 3)
+    angles = angle_table(C11)
+    for i, j, k in angles:
+        v = 0.160 if (element_list[i] == "H" or element_list[k] == "H") else 0.250
+        add(i, j, v); add(j, k, v)
+    for i, j, k, l in dihedral_table(C11, angles):
+        v = 0.0023 - 1 * 0.07 * (np.linalg.norm(coord[j] - coord[k]) - (cov[j] + cov[k]))
+        add(i, j, v); add(j, k, v); add(k, l, v)
+    H = np.zeros((3 * N, 3 * N))
+    for (i, j), k in K.items():
+        u = (coord[i] - coord[j]) / np.linalg.norm(coord[i] - coord[j])
+        blk = k * np.outer(u, u)
+        H[3 * i:3 * i + 3, 3 * i:3 * i + 3] += blk
+        H[3 * j:3 * j + 3, 3 * j:3 * j + 3] += blk
+        H[3 * i:3 * i + 3, 3 * j:3 * j + 3] -= blk
+        H[3 * j:3 * j + 3, 3 * i:3 * i + 3] -= blk
+    H = np.nan_to_num(H, nan=0.0)
+    return pj.project_hessian_trrot(H, coord) if project else H
+
+
 def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
     """ApproxHessian.main: the three Fischer models are restated; the reference's substring tests come in this order
     (approx_hessian.py:35-91): gfnff, gfn0xtb, fischerd3old, fischerd3, fischerd4, schlegel*, swart*, lindh*, fischer, morse."""
@@ -350,7 +414,11 @@ def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fi
         return fischer_d3_old(coord, element_list)
     if "fischerd3" in name:
         return fischer_d3(coord, element_list)
-    if any(k in name for k in ("fischerd4", "schlegel", "swart", "lindh")):
+    if "schlegeld3" in name or "schlegeld4" in name:
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
+    if "schlegel" in name:
+        return schlegel(coord, element_list)
+    if any(k in name for k in ("fischerd4", "swart", "lindh")):
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
     if "fischer" in name:
         return fischer_plain(coord, element_list)

@@ -351,6 +351,7 @@ def g10b_model_hessian_variants():
     from multioptpy.ModelHessian.fischerd3 import FischerD3ApproxHessian
     from multioptpy.ModelHessian.fischer import FischerApproxHessian
     from multioptpy.ModelHessian.approx_hessian import ApproxHessian
+    from multioptpy.ModelHessian.schlegel import SchlegelApproxHessian
     z = np.load(os.path.join(HERE, "g10_model_hessian.npz"))
     out = {"tags": z["tags"]}
     for tag in z["tags"]:
@@ -361,6 +362,9 @@ def g10b_model_hessian_variants():
             H3d = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="fischerd3")
             Hp = FischerApproxHessian().main(x.copy(), list(elems), g)
             Hpd = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="fischer")
+            Hs = SchlegelApproxHessian().main(x.copy(), list(elems), g)
+            Hsd = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="schlegel")
+        out[tag + "_Hsch"], out[tag + "_Hschdisp"] = np.array(Hs), np.array(Hsd)
         out[tag + "_x"], out[tag + "_elems"] = x, z[tag + "_elems"]
         out[tag + "_Hd3"], out[tag + "_Hd3disp"], out[tag + "_Hplain"], out[tag + "_Hplaindisp"] = np.array(H3), np.array(H3d), np.array(Hp), np.array(Hpd)
     np.savez_compressed(os.path.join(HERE, "g10b_model_hessian_variants.npz"), **out)
