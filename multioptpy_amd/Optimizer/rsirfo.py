@@ -15,8 +15,6 @@ import ctypes as C
 
 import numpy as np
 
-_KEEP_ZERO_BIAS = __import__("os").environ.get("MOPT_KEEP_ZERO_BIAS") == "1"      # developer switch: upload an all-zero bias Hessian anyway
-
 from .. import _abi
 from .._lib import lib, ctx, check, f64, ptr
 
@@ -187,8 +185,6 @@ class RSIRFO:
             raise ValueError("Hessian must be a (3N,3N) ndarray")
         Hc = f64(H)
         Bh = None if self.bias_hessian is None else f64(self.bias_hessian)
-        if Bh is not None and not _KEEP_ZERO_BIAS and not Bh.any():
-            Bh = None                                        # H + 0 is H bit for bit: no upload, no n^2 pass for an all-zero bias (the usual case)
         be = np.array([float(B_e)])
         step = np.empty((1, n))
         Hin = np.empty((n, n)) if do_update else None

@@ -12,8 +12,6 @@ import ctypes as C
 
 import numpy as np
 
-_KEEP_ZERO_BIAS = __import__("os").environ.get("MOPT_KEEP_ZERO_BIAS") == "1"      # developer switch: upload an all-zero bias Hessian anyway
-
 from .. import _abi
 from .._lib import lib, ctx, check, f64, ptr
 
@@ -170,8 +168,6 @@ class EnhancedRSPRFO:
         ts = f64(self.ts_mode_eigvec).reshape(-1) if self.ts_mode_eigvec is not None else None
         H = f64(self.hessian)
         Bh = None if self.bias_hessian is None else f64(self.bias_hessian)
-        if Bh is not None and not _KEEP_ZERO_BIAS and not Bh.any():
-            Bh = None                                        # H + 0 is H bit for bit: no upload, no n^2 pass for an all-zero bias
         step = np.empty(n)
         Hout = np.empty((n, n))
         tsout = np.zeros(n)
