@@ -327,12 +327,16 @@ int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *cov, int n1, 
  *   MOPT_MODEL_FISCHER       FischerApproxHessian.main (ModelHessian/fischer.py:216-236): internal-coordinate terms only.
  *   MOPT_MODEL_SCHLEGEL      SchlegelApproxHessian.main (ModelHessian/schlegel.py:66-144): H = B^T K B over the all-pairs stretch rows
  *                            (Coordinate/redundant_coordinate.py:15-43), K filled from the bond / angle / dihedral tables.
+ *   MOPT_MODEL_MORSE         MorseApproxHessian.create_model_hessian (ModelHessian/morse.py:50-106): all-pairs Morse curvature with
+ *                            r_eq from the GNB radii (Parameters/gnb.py:39-55), De = 0.10, a = 0.20; symmetrised, never projected
+ *                            (the reference returns it unprojected: `project` is ignored).
  * X: batch x N x 3 (bohr).  par: six arrays of N doubles in a row -- covalent radius, C6, van-der-Waals radius, r4/r2, reference
  * coordination number of every atom in atomic units (the values of multioptpy/Parameters: covalent_radii_lib, D2_C6_coeff_lib,
- * D2_VDW_radii_lib, D3Parameters.get_r4r2; fischerd3.py:29-44 ref_cn_map, 4 for elements it does not list) and Schlegel's element
- * code (row of his B table as schlegel.py:27-63 assigns it, + 8 for hydrogen).  d3: {s6, s8, a1, a2}.
+ * D2_VDW_radii_lib, D3Parameters.get_r4r2; fischerd3.py:29-44 ref_cn_map, 4 for elements it does not list) and one model-specific array:
+ * Schlegel's element code (row of his B table as schlegel.py:27-63 assigns it, + 8 for hydrogen) or, for MOPT_MODEL_MORSE, the GNB radius.
+ * d3: {s6, s8, a1, a2}.
  * project = 0 skips the TR/rot projection.  H: batch x 3N x 3N. */
-enum { MOPT_MODEL_FISCHERD3OLD = 0, MOPT_MODEL_FISCHERD3 = 1, MOPT_MODEL_FISCHER = 2, MOPT_MODEL_SCHLEGEL = 3 };
+enum { MOPT_MODEL_FISCHERD3OLD = 0, MOPT_MODEL_FISCHERD3 = 1, MOPT_MODEL_FISCHER = 2, MOPT_MODEL_SCHLEGEL = 3, MOPT_MODEL_MORSE = 4 };
 int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H);
 /* The same for the owned images of a band, from the geometries last uploaded, straight into the band's Hessians in HBM
  * (the reference recomputes the model every -mfc band steps and hands it over in tmp_hessian_{i}.npy, neb.py:515-523). */

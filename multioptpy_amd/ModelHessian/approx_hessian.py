@@ -17,7 +17,7 @@ import numpy as np
 from .. import _lib
 from .._lib import lib, check, f64, ptr
 
-MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER, MODEL_SCHLEGEL = 0, 1, 2, 3
+MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER, MODEL_SCHLEGEL, MODEL_MORSE = 0, 1, 2, 3, 4
 _TAB = None
 
 
@@ -37,14 +37,15 @@ def _schlegel_code(e, order):
     return row + (8 if e == "H" else 0)
 
 
-def element_parameters(element_list):
-    """(par, d3): par = [cov | c6 | vdw | r4r2 | refcn | schlegel code] as one (6 N,) array, d3 = (s6, s8, a1, a2) -- the arguments
-    of the C ABI."""
+def element_parameters(element_list, kind=MODEL_FISCHERD3OLD):
+    """(par, d3): par = [cov | c6 | vdw | r4r2 | refcn | model-specific] as one (6 N,) array, d3 = (s6, s8, a1, a2) -- the arguments
+    of the C ABI; the last array is Schlegel's element code, or the GNB radius for the Morse model."""
     t = _tables()
     el = t["elements"]
     try:
         par = np.concatenate([np.array([el[str(e)][k] for e in element_list], dtype=np.float64) for k in ("cov", "c6", "vdw", "r4r2", "refcn")]
-                             + [np.array([_schlegel_code(str(e), t["order"]) for e in element_list], dtype=np.float64)])
+                             + [np.array([(el[str(e)]["gnb"] if kind == MODEL_MORSE else _schlegel_code(str(e), t["order"])) for e in element_list],
+                                         dtype=np.float64)])
     except KeyError as e:
         raise KeyError(f"no model-Hessian parameters for element {e}") from None
     d3 = np.array([t["d3"][k] for k in ("s6", "s8", "a1", "a2")], dtype=np.float64)
@@ -67,10 +68,14 @@ def model_kind(approx_hess_type):
         pass
     elif "schlegel" in name:
         kind, base = MODEL_SCHLEGEL, "schlegel"
-    elif not any(k in name for k in ("swart", "lindh")) and "fischer" in name:
+    elif any(k in name for k in ("swart", "lindh")):
+        pass
+    elif "fischer" in name:
         kind, base = MODEL_FISCHER, "fischer"
+    elif "morse" in name:
+        kind, base = MODEL_MORSE, "morse"
     if kind is None:
-        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, fischer, schlegel)")
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, fischer, schlegel, morse)")
     for suffix in ("ts", "sr", "clip"):                  # approx_hessian.py:93-110: modifiers applied after the model
         if suffix in name.replace(base, ""):
             raise NotImplementedError(f"model Hessian modifier '{suffix}' is not available on the device")
@@ -85,7 +90,7 @@ class ApproxHessian:
         kind = model_kind(approx_hess_type)
         X = f64(coord).reshape(-1, 3)
         N = X.shape[0]
-        par, d3 = element_parameters(element_list)
+        par, d3 = element_parameters(element_list, kind)
         H = np.empty((3 * N, 3 * N))
         c = _lib.ctx(self.device)
         check(lib().mopt_model_hessian(c, kind, N, 1, ptr(X), ptr(par), ptr(d3), 1, ptr(H)), c)
@@ -96,7 +101,7 @@ class ApproxHessian:
         kind = model_kind(approx_hess_type)
         X = f64(coords)
         I, N = X.shape[0], X.shape[1]
-        par, d3 = element_parameters(element_list)
+        par, d3 = element_parameters(element_list, kind)
         H = np.empty((I, 3 * N, 3 * N))
         c = _lib.ctx(self.device)
         check(lib().mopt_model_hessian(c, kind, N, I, ptr(X), ptr(par), ptr(d3), 1 if project else 0, ptr(H)), c)

@@ -534,7 +534,7 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
 extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par, const double *d3) {
     if (!b || !par || !d3) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
-    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_SCHLEGEL) { ctx->err = "mopt_band_model_hessian: unknown model"; return MOPT_E_ARG; }
+    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_MORSE) { ctx->err = "mopt_band_model_hessian: unknown model"; return MOPT_E_ARG; }
     if (!b->uploaded) { ctx->err = "mopt_band_model_hessian: no geometries uploaded"; return MOPT_E_STATE; }
     hipSetDevice(ctx->device);
     double *d_par = nullptr;

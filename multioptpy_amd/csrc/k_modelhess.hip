@@ -7,6 +7,9 @@
 //                         number (fischerd3.py:46-60, 224-229; k_mh_connect), stricter guards (fischerd3.py:88, 144-155)
 //   MOPT_MODEL_FISCHER    FischerApproxHessian.main (fischer.py:216-236): no pair term, no angle guard, cross-product linearity test
 //                         of the torsions (fischer.py:140-170), no sin^2 damping
+//   MOPT_MODEL_MORSE      MorseApproxHessian.create_model_hessian (morse.py:50-106): every atom pair a Morse bond, k = De a^2 (4 e^-2x - 2 e^-x),
+//                         x = a (r - r_i - r_j) with the GNB radii (par[5 N + i]), De = 0.10, a = 0.20; k u u^T blocks in the pair loop of
+//                         k_mh_assemble, symmetrised, NOT TR/rot-projected (the reference returns it unprojected)
 //   MOPT_MODEL_SCHLEGEL   SchlegelApproxHessian.main (schlegel.py:66-144): H = B^T K B over the all-pairs stretch rows of
 //                         redundant_coordinate.py:15-43 with a diagonal K filled from the three tables -- every contribution lands on a
 //                         bonded pair, so the model is "one spring per bond": the bond lane of k_mh_internals walks the angle and
@@ -324,7 +327,7 @@ __global__ void __launch_bounds__(128) k_mh_assemble(int kind, int N, const doub
     const double *x = X_ + (size_t)b * N * 3;
     const double *c6 = par + N, *vdw = par + 2 * N, *r4 = par + 3 * N;
     const int *cnt = w.cnt + 4 * b;
-    const int ne = cnt[0] + cnt[1] + cnt[2];
+    const int ne = (kind == MOPT_MODEL_MORSE) ? 0 : cnt[0] + cnt[1] + cnt[2];
     const int *atoms = w.atoms + (size_t)b * w.cap * 4;
     const double *fcv = w.fc + (size_t)b * w.cap, *bvv = w.bv + (size_t)b * w.cap * 12;
     for (int i = tid; i < 3 * n; i += nt) row[i] = 0.0;
@@ -359,6 +362,22 @@ __global__ void __launch_bounds__(128) k_mh_assemble(int kind, int N, const doub
     const double *c6s = w.c6s + (size_t)b * N;
     const V3 xm = ld3(x, m);
     for (int j = tid; j < ((kind == MOPT_MODEL_FISCHER || kind == MOPT_MODEL_SCHLEGEL) ? 0 : N); j += nt) {
+        if (kind == MOPT_MODEL_MORSE) {                      // morse.py:70-100 (all pairs; De = 0.10, a = 0.20: the dispatcher's defaults)
+            if (j == m) continue;
+            const V3 rv = sub(xm, ld3(x, j));
+            const double r = norm(rv);
+            if (!(r > 1.0e-12)) continue;
+            const double *gnb = par + 5 * (size_t)N;
+            const double xx = 0.20 * (r - (gnb[m] + gnb[j]));
+            const double k = 0.10 * (0.20 * 0.20) * (-2.0 * exp(-xx) + 4.0 * exp(-2.0 * xx));
+            const double u[3] = {rv.x / r, rv.y / r, rv.z / r};
+            double *rr[3] = {row + 3 * j, row + n + 3 * j, row + 2 * n + 3 * j};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { const double blk = k * (u[p] * u[q]); rr[p][q] -= blk; acc[3 * p + q] += blk; }
+            continue;
+        }
         if (j == m || c13[j]) continue;
         const V3 rv = sub(xm, ld3(x, j));
         const double r = norm(rv);
@@ -399,7 +418,7 @@ __global__ void __launch_bounds__(128) k_mh_assemble(int kind, int N, const doub
 
 }  // namespace mopt
 
-// kind: MOPT_MODEL_*.  d_X: [batch][N][3] bohr; d_par: cov[N], c6[N], vdw[N], r4r2[N], refcn[N], schlegel code[N]; d3: s6, s8, a1, a2.  Result: d_A = the projected model Hessian
+// kind: MOPT_MODEL_*.  d_X: [batch][N][3] bohr; d_par: cov[N], c6[N], vdw[N], r4r2[N], refcn[N], model-specific[N] (Schlegel's element code / GNB radius); d3: s6, s8, a1, a2.  Result: d_A = the projected model Hessian
 // (d_H holds the unprojected, unsymmetrised assembly).  d_Q, d_W: 6 n doubles per image.  Returns MOPT_E_ARG when an image has more
 // internal coordinates than the tables hold.
 int mopt_launch_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
@@ -437,6 +456,6 @@ int mopt_launch_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const d
     if (e != hipSuccess) { ctx->err = std::string("model Hessian kernels: ") + hipGetErrorString(e); return MOPT_E_DEVICE; }
     for (int b = 0; b < batch; ++b) if (cnt[4 * b + 3]) { ctx->err = "model Hessian: more internal coordinates than the tables hold (16 N bonds, 96 N angles, 192 N dihedrals)"; rc = MOPT_E_ARG; }
     if (rc != MOPT_OK) return rc;
-    if (project) return mopt_launch_project_hess(ctx, n, batch, d_H, nullptr, d_X, d_Q, d_W, d_A);
+    if (project && kind != MOPT_MODEL_MORSE) return mopt_launch_project_hess(ctx, n, batch, d_H, nullptr, d_X, d_Q, d_W, d_A);
     return mopt_launch_sym_add(ctx, n, batch, d_H, nullptr, d_A);
 }

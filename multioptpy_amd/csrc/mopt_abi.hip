@@ -314,7 +314,7 @@ extern "C" int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *co
 
 extern "C" int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H) {
     if (!ctx) return MOPT_E_ARG;
-    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_SCHLEGEL) { ctx->err = "mopt_model_hessian: unknown model"; return MOPT_E_ARG; }
+    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_MORSE) { ctx->err = "mopt_model_hessian: unknown model"; return MOPT_E_ARG; }
     if (bad_dims(ctx, 3 * N, batch) || N < 1 || !X || !par || !d3 || !H) return MOPT_E_ARG;
     hipSetDevice(ctx->device);
     const int n = 3 * N;

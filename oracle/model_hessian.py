@@ -4,6 +4,7 @@
   FischerD3ApproxHessian.main       multioptpy/ModelHessian/fischerd3.py:177-304      (coordination-number scaled D3 pairs)
   FischerApproxHessian.main         multioptpy/ModelHessian/fischer.py:216-236        (no dispersion term)
   SchlegelApproxHessian.main        multioptpy/ModelHessian/schlegel.py:66-144        (pair springs from the connectivity tables)
+  MorseApproxHessian.create_model_hessian  multioptpy/ModelHessian/morse.py:50-106    (all-pairs Morse curvature, unprojected)
 with its helpers: BondConnectivity (Utils/bond_connectivity.py:7-135), stretch2 / bend2 / torsion2 (ModelHessian/calc_params.py:139-227).
 Pinned by tests/golden/g10_model_hessian.npz and g10b_model_hessian_variants.npz (outputs of the reference itself).  Coordinates in bohr."""
 import json
@@ -404,6 +405,29 @@ def schlegel(coord, element_list, project=True):
     return pj.project_hessian_trrot(H, coord) if project else H
 
 
+def morse(coord, element_list, De=0.10, a=0.20):
+    """MorseApproxHessian.create_model_hessian (morse.py:50-106): every atom pair is a Morse bond with r_eq = the sum of the GNB radii
+    (Parameters/gnb.py:39-55); k = De a^2 (-2 e^-x + 4 e^-2x), x = a (r - r_eq); H = sum k u u^T blocks, symmetrised, NOT projected."""
+    coord = np.asarray(coord, dtype=float).reshape(-1, 3)
+    N = len(coord)
+    t = tables()["elements"]
+    gnb = np.array([t[e]["gnb"] for e in element_list], dtype=float)
+    H = np.zeros((3 * N, 3 * N))
+    for i in range(N - 1):
+        for j in range(i + 1, N):
+            v = coord[j] - coord[i]
+            r = np.linalg.norm(v)
+            x = a * (r - (gnb[i] + gnb[j]))
+            k = De * a ** 2 * (-2.0 * np.exp(-x) + 4.0 * np.exp(-2.0 * x))
+            u = v / r if r > 1e-12 else np.zeros(3)
+            blk = k * np.outer(u, u)
+            H[3 * i:3 * i + 3, 3 * i:3 * i + 3] += blk
+            H[3 * j:3 * j + 3, 3 * j:3 * j + 3] += blk
+            H[3 * i:3 * i + 3, 3 * j:3 * j + 3] -= blk
+            H[3 * j:3 * j + 3, 3 * i:3 * i + 3] -= blk
+    return 0.5 * (H + H.T)
+
+
 def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
     """ApproxHessian.main: the three Fischer models are restated; the reference's substring tests come in this order
     (approx_hessian.py:35-91): gfnff, gfn0xtb, fischerd3old, fischerd3, fischerd4, schlegel*, swart*, lindh*, fischer, morse."""
@@ -422,4 +446,6 @@ def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fi
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
     if "fischer" in name:
         return fischer_plain(coord, element_list)
+    if "morse" in name:
+        return morse(coord, element_list)
     raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")

@@ -364,6 +364,8 @@ def g10b_model_hessian_variants():
             Hpd = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="fischer")
             Hs = SchlegelApproxHessian().main(x.copy(), list(elems), g)
             Hsd = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="schlegel")
+            Hm = ApproxHessian().main(x.copy(), list(elems), g, approx_hess_type="morse")
+        out[tag + "_Hmorse"] = np.array(Hm)
         out[tag + "_Hsch"], out[tag + "_Hschdisp"] = np.array(Hs), np.array(Hsd)
         out[tag + "_x"], out[tag + "_elems"] = x, z[tag + "_elems"]
         out[tag + "_Hd3"], out[tag + "_Hd3disp"], out[tag + "_Hplain"], out[tag + "_Hplaindisp"] = np.array(H3), np.array(H3d), np.array(Hp), np.array(Hpd)

@@ -362,8 +362,8 @@ def test_model_hessian_fischerd3old_vs_reference():
 
 
 def test_model_hessian_fischer_variants_vs_reference():
-    """G10b: the device's FischerD3 (coordination-number scaled pairs, fischerd3.py), plain Fischer (fischer.py) and Schlegel
-    (schlegel.py) model Hessians against the reference's own outputs (<= 1e-8), through the plugin class; a batch of two geometries; a 100-atom argon cluster
+    """G10b: the device's FischerD3 (coordination-number scaled pairs, fischerd3.py), plain Fischer (fischer.py), Schlegel
+    (schlegel.py) and Morse (morse.py, unprojected) model Hessians against the reference's own outputs (<= 1e-8), through the plugin class; a batch of two geometries; a 100-atom argon cluster
     (pair terms with every atom's C6 scaled) and the alkane chain against the oracle; the band entry point."""
     import os
     from oracle import model_hessian as mh
@@ -373,14 +373,14 @@ def test_model_hessian_fischer_variants_vs_reference():
     worst = 0.0
     for t in z["tags"]:
         el = [str(e) for e in z[t + "_elems"]]
-        for name, key in (("fischerd3", "_Hd3"), ("fischer", "_Hplain"), ("schlegel", "_Hsch")):
+        for name, key in (("fischerd3", "_Hd3"), ("fischer", "_Hplain"), ("schlegel", "_Hsch"), ("morse", "_Hmorse")):
             H = ApproxHessian().main(z[t + "_x"], el, np.zeros_like(z[t + "_x"]), approx_hess_type=name)
             err = np.abs(H - z[t + key]).max()
             worst = max(worst, err)
             assert err < 1e-8, (t, name, err)
     a, b = "aldol_rxn", "aldol_jitter"
     el = [str(e) for e in z[a + "_elems"]]
-    for name, key in (("fischerd3", "_Hd3"), ("fischer", "_Hplain"), ("schlegel", "_Hsch")):
+    for name, key in (("fischerd3", "_Hd3"), ("fischer", "_Hplain"), ("schlegel", "_Hsch"), ("morse", "_Hmorse")):
         Hb = ApproxHessian().batch(np.array([z[a + "_x"], z[b + "_x"]]), el, approx_hess_type=name)
         assert np.abs(Hb[0] - z[a + key]).max() < 1e-8 and np.abs(Hb[1] - z[b + key]).max() < 1e-8
     x = cases.cluster(100)
@@ -421,7 +421,7 @@ def test_model_hessian_large_cluster_vs_oracle():
     ref = mh.fischer_d3_old(x, el)
     assert np.abs(ref).max() > 0.1
     assert np.abs(H - ref).max() < 1e-9, np.abs(H - ref).max()
-    for name, fn in (("fischerd3", mh.fischer_d3), ("fischer", mh.fischer_plain), ("schlegel", mh.schlegel)):
+    for name, fn in (("fischerd3", mh.fischer_d3), ("fischer", mh.fischer_plain), ("schlegel", mh.schlegel), ("morse", mh.morse)):
         H = ApproxHessian().main(x, el, None, name)
         ref = fn(x, el)
         assert np.abs(H - ref).max() < 1e-9, (name, np.abs(H - ref).max())

@@ -365,6 +365,7 @@ def test_g10b_model_hessian_variants_oracle_vs_reference():
         Hs = mh.approx_hessian(z[t + "_x"], el, None, "schlegel")
         assert np.abs(Hs - z[t + "_Hsch"]).max() < 1e-13, t
         assert np.array_equal(z[t + "_Hsch"], z[t + "_Hschdisp"]), t
+        assert np.abs(mh.approx_hessian(z[t + "_x"], el, None, "morse") - z[t + "_Hmorse"]).max() < 1e-13, t
         assert np.array_equal(z[t + "_Hd3"], z[t + "_Hd3disp"]) and np.array_equal(z[t + "_Hplain"], z[t + "_Hplaindisp"]), t
     for t in ("aldol_rxn", "claisen_rearrengment", "ar13"):
         assert np.abs(z[t + "_Hd3"] - zo[t + "_H"]).max() > 1e-5, t
