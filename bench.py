@@ -154,11 +154,12 @@ SIDE_FAMILIES = {"halo", "eigh_dc", "rfo_scalar", "eigh_small", "eigh_early", "a
 
 
 def library_stamp():
-    """Identify the loaded kernel library: sha1 over the HIP sources it was built from (profiles/traffic.json carries the same)."""
+    """Identify the dominant kernel's code: sha1 over the translation unit of the eigen-solver's tridiagonalisation (k_tridiag.hip) and
+    every header of the library (profiles/traffic.json carries the same; kernels of other files do not enter the counter figure)."""
     import glob
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.h*"))):
+    for f in sorted([os.path.join(ROOT, "multioptpy_amd", "csrc", "k_tridiag.hip")] + glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.h*"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:12]
 
