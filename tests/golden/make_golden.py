@@ -374,6 +374,31 @@ def g10b_model_hessian_variants():
 
 
 
+def g14_keep_pot():
+    """G14: StructKeepPotential.calc_energy with its gradient and Hessian as the reference obtains them (torch.func.jacrev / hessian,
+    Potential/potential.py:127-152): bonded and distant pairs, stretched and compressed, parameters from the constructor and from
+    bias_pot_params."""
+    import torch
+    from multioptpy.Potential.keep_potential import StructKeepPotential
+    out = {}
+    elems, xyz = _read_xyz("/root/reference/test/aldol_rxn.xyz")
+    x = xyz / cases.BOHR2ANG
+    cases_ = [("a", x, [1, 2], 0.1, 1.0, False), ("b", x, [3, 11], 0.5, 4.5, True), ("c", x, [7, 2], 2.0, 0.3, False),
+              ("d", cases.cluster(13), [1, 13], 0.05, 8.0, True)]
+    for tag, xb, pair, k, r0, via_params in cases_:
+        pot = StructKeepPotential(keep_pot_spring_const=k, keep_pot_distance=r0, keep_pot_atom_pairs=pair)
+        g = torch.tensor(xb, dtype=torch.float64)
+        par = torch.tensor([k, r0], dtype=torch.float64) if via_params else []
+        e = pot.calc_energy(g, par)
+        grad = torch.func.jacrev(pot.calc_energy, argnums=0)(g, par)
+        hess = torch.func.hessian(pot.calc_energy, argnums=0)(g, par).reshape(3 * len(xb), 3 * len(xb))
+        out[tag + "_x"], out[tag + "_pair"], out[tag + "_k"], out[tag + "_r0"] = xb, np.array(pair), np.array(k), np.array(r0)
+        out[tag + "_E"], out[tag + "_g"], out[tag + "_H"] = np.array(float(e)), grad.detach().numpy(), hess.detach().numpy()
+    out["tags"] = np.array([c[0] for c in cases_])
+    np.savez_compressed(os.path.join(HERE, "g14_keep_pot.npz"), **out)
+    print("G14:", len(cases_), "cases")
+
+
 def g11_afir():
     """G11: AFIRPotential.calc_energy with its gradient and Hessian as the reference obtains them (torch.func.jacrev / hessian,
     Potential/potential.py:127-152) for several geometries, fragment pairs and gamma values (kJ/mol, both signs and zero)."""
@@ -883,7 +908,7 @@ def g8_nebmain():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g11", "g12", "g13", "g14"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -894,6 +919,8 @@ if __name__ == "__main__":
         g3_rsprfo()
     if "g10" in which:
         g10_model_hessian()
+    if "g14" in which:
+        g14_keep_pot()
     if "g10b" in which:
         g10b_model_hessian_variants()
     if "g11" in which:

@@ -503,6 +503,28 @@ print("ok")
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_keep_pot_bias_vs_reference():
+    """G14: the device's harmonic distance restraint (mopt_keep_pot through the StructKeepPotential plugin class) against the reference's
+    torch-autograd energy / gradient / Hessian (<= 1e-10), and two restraints that share an atom in one call against the oracle's sum."""
+    import os
+    from oracle import keep_pot as kp
+    from multioptpy_amd.Potential.keep_potential import StructKeepPotential, keep_pot_sum
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g14_keep_pot.npz"))
+    for t in z["tags"]:
+        pair = [int(v) for v in z[t + "_pair"]]
+        pot = StructKeepPotential(keep_pot_spring_const=float(z[t + "_k"]), keep_pot_distance=float(z[t + "_r0"]), keep_pot_atom_pairs=pair)
+        E, g, H = pot.calc_energy_gradient_hessian(z[t + "_x"], [])
+        assert abs(E - float(z[t + "_E"])) < 1e-12, t
+        assert np.abs(g - z[t + "_g"]).max() < 1e-12 and np.abs(H - z[t + "_H"]).max() < 1e-10, t
+        E2, _, _ = pot.calc_energy_gradient_hessian(z[t + "_x"], [2.0 * float(z[t + "_k"]), float(z[t + "_r0"])])
+        assert abs(E2 - 2.0 * float(z[t + "_E"])) < 1e-12
+    x = z["a_x"]
+    E, g, H = keep_pot_sum(x, [[1, 2], [2, 5], [5, 1]], [0.1, 0.3, 0.2], [1.0, 2.0, 1.5])
+    ref = [kp.keep_pot(x, p, k, r) for p, k, r in (([1, 2], 0.1, 1.0), ([2, 5], 0.3, 2.0), ([5, 1], 0.2, 1.5))]
+    assert abs(E - sum(r[0] for r in ref)) < 1e-13
+    assert np.abs(g - sum(r[1] for r in ref)).max() < 1e-13 and np.abs(H - sum(r[2] for r in ref)).max() < 1e-12
+
+
 def test_afir_bias_vs_reference():
     """G11: AFIR bias energy / gradient / Hessian on the device against the reference's torch-autograd values (<= 1e-8; ~1e-16)."""
     import os

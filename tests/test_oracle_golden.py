@@ -372,6 +372,15 @@ def test_g10b_model_hessian_variants_oracle_vs_reference():
         assert np.abs(z[t + "_Hplain"] - zo[t + "_H"]).max() > 1e-5, t
 
 
+def test_g14_keep_pot_oracle_vs_reference():
+    """G14: StructKeepPotential energy, gradient and Hessian of the reference (torch autograd) against the oracle's analytic forms."""
+    from oracle import keep_pot as kp
+    z = np.load(os.path.join(G, "g14_keep_pot.npz"))
+    for t in z["tags"]:
+        E, g, H = kp.keep_pot(z[t + "_x"], [int(v) for v in z[t + "_pair"]], float(z[t + "_k"]), float(z[t + "_r0"]))
+        assert abs(E - float(z[t + "_E"])) < 1e-13 and np.abs(g - z[t + "_g"]).max() < 1e-13 and np.abs(H - z[t + "_H"]).max() < 1e-12, t
+
+
 def test_g11_afir_oracle_vs_reference():
     """G11: AFIR energy, gradient and Hessian (the reference's torch autograd outputs) against the oracle's analytic form."""
     from oracle import afir, model_hessian as mh
