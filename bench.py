@@ -159,7 +159,8 @@ def library_stamp():
     import glob
     import hashlib
     h = hashlib.sha1()
-    for f in sorted([os.path.join(ROOT, "multioptpy_amd", "csrc", "k_tridiag.hip")] + glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.h*"))):
+    for f in sorted([os.path.join(ROOT, "multioptpy_amd", "csrc", "k_tridiag.hip")] + glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.h")) +
+                    glob.glob(os.path.join(ROOT, "multioptpy_amd", "csrc", "*.hpp"))):
         h.update(open(f, "rb").read())
     return h.hexdigest()[:12]
 
