@@ -59,7 +59,7 @@ class ConvergenceChecker:
 
 def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, saddle_order=0, NSTEP=300, FC_COUNT=-1,
                   max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False, model_hessian=None,
-                  MFC_COUNT=50, afir=None):
+                  MFC_COUNT=50, afir=None, keep_pot=None):
     """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy)."""
     natom = len(element_list)
     geometry = np.array(start_geometry_ang, dtype="float64") / BOHR2ANGSTROMS
@@ -107,6 +107,11 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
             from .Potential.AFIR_potential import AFIRPotential
             pot = AFIRPotential(AFIR_gamma=afir["gamma"], AFIR_Fragm_1=afir["fragm_1"], AFIR_Fragm_2=afir["fragm_2"], element_list=element_list)
             bias_energy, bias_gradient, bias_hessian = pot.calc_energy_gradient_hessian(geometry, [afir["gamma"]])
+        if keep_pot:
+            # harmonic distance restraints (`-kp k r0 i,j`, Potential/keep_potential.py): list of dict(pair=[i, j] 1-based, k=..., r0=... angstrom)
+            from .Potential.keep_potential import keep_pot_sum
+            ke, kg, kh = keep_pot_sum(geometry, [p["pair"] for p in keep_pot], [p["k"] for p in keep_pot], [p["r0"] for p in keep_pot])
+            bias_energy, bias_gradient, bias_hessian = bias_energy + ke, bias_gradient + kg, bias_hessian + kh
         if it == 0:                                                     # _save_init_geometry (optimization.py:2206-2217)
             centre = tools.calc_center(geometry, element_list)
             pre_geometry = (geometry - centre) - centre

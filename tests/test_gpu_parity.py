@@ -508,6 +508,45 @@ def test_optmain_driver_vs_reference(tag):
     print("optmain", tag, "worst move-vector deviation from the reference", worst)
 
 
+@pytest.mark.parametrize("kind", ["keep", "afir", "both"])
+def test_optmain_driver_with_bias_vs_oracle(kind):
+    """a23 + f3: the in-memory optmain iteration with bias potentials -- harmonic distance restraints (mopt_keep_pot) and / or the AFIR
+    term (mopt_afir): bias energy and gradient added to the calculator's, bias Hessian handed to the optimizer -- against the oracle's
+    driver with the oracle's analytic bias (both pinned by the reference's autograd outputs, G11 / G14): six iterations on Ar7."""
+    import cases
+    from oracle import driver, projection as pj, afir as oafir, keep_pot as okp, model_hessian as mh
+    from multioptpy_amd import drivers
+    N = 7
+    x0 = cases.cluster(N, jitter=0.2) * cases.BOHR2ANG
+    el = ["Ar"] * N
+    cov = mh.element_params(el)["cov"]
+    kp = [dict(pair=[1, 4], k=0.05, r0=3.2), dict(pair=[4, 6], k=0.1, r0=4.5)] if kind in ("keep", "both") else None
+    af = dict(gamma=40.0, fragm_1=[1, 2, 3], fragm_2=[5, 6, 7]) if kind in ("afir", "both") else None
+
+    def bias(x):
+        E, g, H = 0.0, np.zeros((N, 3)), np.zeros((3 * N, 3 * N))
+        if af:
+            e1, g1, h1 = oafir.afir(x, cov, af["fragm_1"], af["fragm_2"], af["gamma"])
+            E, g, H = E + e1, g + g1, H + h1
+        for p in kp or []:
+            e1, g1, h1 = okp.keep_pot(x, p["pair"], p["k"], p["r0"])
+            E, g, H = E + e1, g + g1, H + h1
+        return E, g, H
+
+    ra, rb = [], []
+    drivers.optmain_steps(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=ra, afir=af, keep_pot=kp)
+    driver.run_optmain(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=rb, bias=bias)
+    assert len(ra) == len(rb) >= 3
+    worst = 0.0
+    for a, b in zip(ra, rb):
+        for key in ("geom", "B_g", "mv", "aligned", "H"):
+            worst = max(worst, float(np.abs(np.asarray(a[key]) - np.asarray(b[key])).max()))
+        assert abs(a["B_e"] - b["B_e"]) < 1e-10 and abs(a["tr"] - b["tr"]) < 1e-10
+    assert worst < 1e-8, worst
+    assert np.abs(ra[0]["B_g"] - cases.lj(ra[0]["geom"])[1]).max() > 1e-4      # the bias is really there
+    print("biased optmain", kind, "worst deviation from the oracle's driver", worst)
+
+
 @pytest.mark.parametrize("tag", ["n", "e", "f", "s", "a", "c"])
 def test_nebmain_driver_vs_reference(tag):
     """a23: the in-memory nebmain iteration (RFO branch) on the device path against the reference driver's own band
