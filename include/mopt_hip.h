@@ -316,9 +316,11 @@ int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *para
 int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *cov, int n1, const int *frag1, int n2, const int *frag2, double alpha,
               double *E, double *grad, double *H);
 
-/* Harmonic distance restraints E = sum_p 1/2 k_p (r_p - r0_p)^2 (StructKeepPotential.calc_energy, Potential/keep_potential.py:21-58; the
- * reference holds one pair per object and differentiates with torch, Potential/potential.py:127-152).  X: N x 3 (bohr); pairs: npairs x 2
- * 0-based atoms; kr: npairs x 2 = (spring constant hartree / bohr^2, r0 in bohr).  Out: E (1), grad (N x 3), H (3N x 3N). */
+/* Distance restraints E = sum_p V_p(r_p): harmonic 1/2 k (r - r0)^2 (StructKeepPotential.calc_energy, Potential/keep_potential.py:21-58) or
+ * anharmonic D (1 - exp(-sqrt(k / 2D) (r - r0)))^2 (StructAnharmonicKeepPotential.calc_energy, Potential/anharmonic_keep_potential.py:13-27);
+ * the reference holds one pair per object and differentiates with torch, Potential/potential.py:127-152.  X: N x 3 (bohr); pairs: npairs x 2
+ * 0-based atoms; kr: npairs x 3 = (spring constant hartree / bohr^2, r0 in bohr, well depth D in hartree: D < 0 = harmonic, D >= 0 =
+ * anharmonic, D = 0 contributes nothing).  Out: E (1), grad (N x 3), H (3N x 3N). */
 int mopt_keep_pot(mopt_ctx *ctx, int N, const double *X, int npairs, const int *pairs, const double *kr, double *E, double *grad, double *H);
 
 /* ---- model Hessians ----------------------------------------------------------------

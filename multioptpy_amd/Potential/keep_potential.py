@@ -16,13 +16,15 @@ from .._lib import lib, check, f64, ptr
 BOHR2ANGSTROMS = 0.52917721067
 
 
-def keep_pot_sum(geom_num_list, pairs_1based, spring_consts, distances_ang, device=None):
-    """E, grad (N, 3), H (3N, 3N) of sum_p 1/2 k_p (r_p - r0_p)^2; pairs as 1-based labels, r0 in angstrom (the reference's units)."""
+def keep_pot_sum(geom_num_list, pairs_1based, spring_consts, distances_ang, device=None, well_depths=None):
+    """E, grad (N, 3), H (3N, 3N) of sum_p 1/2 k_p (r_p - r0_p)^2; pairs as 1-based labels, r0 in angstrom (the reference's units).
+    ``well_depths`` (hartree, one per pair; None or a negative entry = harmonic) selects the anharmonic form D (1 - exp(-sqrt(k / 2D) (r - r0)))^2."""
     X = f64(np.asarray(geom_num_list, dtype=np.float64)).reshape(-1, 3)
     N = X.shape[0]
     pairs = np.ascontiguousarray(np.asarray(pairs_1based, dtype=np.int32).reshape(-1, 2) - 1)
-    kr = np.ascontiguousarray(np.stack([np.asarray(spring_consts, dtype=np.float64).reshape(-1),
-                                        np.asarray(distances_ang, dtype=np.float64).reshape(-1) / BOHR2ANGSTROMS], axis=1))
+    k = np.asarray(spring_consts, dtype=np.float64).reshape(-1)
+    D = -np.ones_like(k) if well_depths is None else np.asarray(well_depths, dtype=np.float64).reshape(-1)
+    kr = np.ascontiguousarray(np.stack([k, np.asarray(distances_ang, dtype=np.float64).reshape(-1) / BOHR2ANGSTROMS, D], axis=1))
     if len(kr) != len(pairs):
         raise ValueError("one spring constant and one distance per atom pair")
     E = np.zeros(1)
@@ -47,6 +49,25 @@ class StructKeepPotential:
     def calc_energy_gradient_hessian(self, geom_num_list, bias_pot_params=(), device=None):
         k, r0 = self._params(bias_pot_params)
         return keep_pot_sum(geom_num_list, [list(self.config["keep_pot_atom_pairs"])[:2]], [k], [r0], device)
+
+    def calc_energy(self, geom_num_list, bias_pot_params=()):
+        return self.calc_energy_gradient_hessian(geom_num_list, bias_pot_params)[0]
+
+
+class StructAnharmonicKeepPotential:
+    """Device counterpart of ``multioptpy.Potential.anharmonic_keep_potential.StructAnharmonicKeepPotential`` (reference
+    anharmonic_keep_potential.py:5-27): E = D (1 - exp(-sqrt(k / 2D) (r - r0)))^2 between two atoms, zero for D = 0.  Constructor keywords
+    as in the reference: anharmonic_keep_pot_spring_const, anharmonic_keep_pot_potential_well_depth, anharmonic_keep_pot_atom_pairs
+    (1-based), anharmonic_keep_pot_distance (angstrom)."""
+
+    def __init__(self, **kwarg):
+        self.config = kwarg
+        self.bohr2angstroms = BOHR2ANGSTROMS
+
+    def calc_energy_gradient_hessian(self, geom_num_list, bias_pot_params=(), device=None):
+        c = self.config
+        return keep_pot_sum(geom_num_list, [list(c["anharmonic_keep_pot_atom_pairs"])[:2]], [float(c["anharmonic_keep_pot_spring_const"])],
+                            [float(c["anharmonic_keep_pot_distance"])], device, well_depths=[float(c["anharmonic_keep_pot_potential_well_depth"])])
 
     def calc_energy(self, geom_num_list, bias_pot_params=()):
         return self.calc_energy_gradient_hessian(geom_num_list, bias_pot_params)[0]

@@ -394,6 +394,23 @@ def g14_keep_pot():
         hess = torch.func.hessian(pot.calc_energy, argnums=0)(g, par).reshape(3 * len(xb), 3 * len(xb))
         out[tag + "_x"], out[tag + "_pair"], out[tag + "_k"], out[tag + "_r0"] = xb, np.array(pair), np.array(k), np.array(r0)
         out[tag + "_E"], out[tag + "_g"], out[tag + "_H"] = np.array(float(e)), grad.detach().numpy(), hess.detach().numpy()
+    from multioptpy.Potential.anharmonic_keep_potential import StructAnharmonicKeepPotential
+    atags = []
+    for tag, xb, pair, k, D, r0 in (("an_a", x, [1, 2], 0.3, 0.15, 1.2), ("an_b", x, [3, 11], 0.1, 0.02, 3.0), ("an_c", cases.cluster(13), [2, 9], 0.2, 0.05, 5.0),
+                                    ("an_zero", x, [1, 2], 0.3, 0.0, 1.2)):
+        pot = StructAnharmonicKeepPotential(anharmonic_keep_pot_spring_const=k, anharmonic_keep_pot_potential_well_depth=D,
+                                            anharmonic_keep_pot_atom_pairs=pair, anharmonic_keep_pot_distance=r0)
+        g = torch.tensor(xb, dtype=torch.float64)
+        e = pot.calc_energy(g, [])
+        if D != 0.0:
+            grad = torch.func.jacrev(pot.calc_energy, argnums=0)(g, []).detach().numpy()
+            hess = torch.func.hessian(pot.calc_energy, argnums=0)(g, []).reshape(3 * len(xb), 3 * len(xb)).detach().numpy()
+        else:                                       # (a constant tensor: the reference's autograd returns zeros)
+            grad, hess = np.zeros_like(xb), np.zeros((3 * len(xb), 3 * len(xb)))
+        out[tag + "_x"], out[tag + "_pair"], out[tag + "_k"], out[tag + "_D"], out[tag + "_r0"] = xb, np.array(pair), np.array(k), np.array(D), np.array(r0)
+        out[tag + "_E"], out[tag + "_g"], out[tag + "_H"] = np.array(float(e)), grad, hess
+        atags.append(tag)
+    out["atags"] = np.array(atags)
     out["tags"] = np.array([c[0] for c in cases_])
     np.savez_compressed(os.path.join(HERE, "g14_keep_pot.npz"), **out)
     print("G14:", len(cases_), "cases")

@@ -518,6 +518,13 @@ def test_keep_pot_bias_vs_reference():
         assert np.abs(g - z[t + "_g"]).max() < 1e-12 and np.abs(H - z[t + "_H"]).max() < 1e-10, t
         E2, _, _ = pot.calc_energy_gradient_hessian(z[t + "_x"], [2.0 * float(z[t + "_k"]), float(z[t + "_r0"])])
         assert abs(E2 - 2.0 * float(z[t + "_E"])) < 1e-12
+    from multioptpy_amd.Potential.keep_potential import StructAnharmonicKeepPotential
+    for t in z["atags"]:                                     # the anharmonic (Morse-type) restraint, anharmonic_keep_potential.py
+        pot = StructAnharmonicKeepPotential(anharmonic_keep_pot_spring_const=float(z[t + "_k"]), anharmonic_keep_pot_potential_well_depth=float(z[t + "_D"]),
+                                            anharmonic_keep_pot_atom_pairs=[int(v) for v in z[t + "_pair"]], anharmonic_keep_pot_distance=float(z[t + "_r0"]))
+        E, g, H = pot.calc_energy_gradient_hessian(z[t + "_x"])
+        assert abs(E - float(z[t + "_E"])) < 1e-12, t
+        assert np.abs(g - z[t + "_g"]).max() < 1e-12 and np.abs(H - z[t + "_H"]).max() < 1e-10, t
     x = z["a_x"]
     E, g, H = keep_pot_sum(x, [[1, 2], [2, 5], [5, 1]], [0.1, 0.3, 0.2], [1.0, 2.0, 1.5])
     ref = [kp.keep_pot(x, p, k, r) for p, k, r in (([1, 2], 0.1, 1.0), ([2, 5], 0.3, 2.0), ([5, 1], 0.2, 1.5))]

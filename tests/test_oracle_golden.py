@@ -379,6 +379,9 @@ def test_g14_keep_pot_oracle_vs_reference():
     for t in z["tags"]:
         E, g, H = kp.keep_pot(z[t + "_x"], [int(v) for v in z[t + "_pair"]], float(z[t + "_k"]), float(z[t + "_r0"]))
         assert abs(E - float(z[t + "_E"])) < 1e-13 and np.abs(g - z[t + "_g"]).max() < 1e-13 and np.abs(H - z[t + "_H"]).max() < 1e-12, t
+    for t in z["atags"]:
+        E, g, H = kp.anharmonic_keep_pot(z[t + "_x"], [int(v) for v in z[t + "_pair"]], float(z[t + "_k"]), float(z[t + "_D"]), float(z[t + "_r0"]))
+        assert abs(E - float(z[t + "_E"])) < 1e-13 and np.abs(g - z[t + "_g"]).max() < 1e-13 and np.abs(H - z[t + "_H"]).max() < 1e-12, t
 
 
 def test_g11_afir_oracle_vs_reference():
