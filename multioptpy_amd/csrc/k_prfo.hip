@@ -301,6 +301,14 @@ __global__ void k_norm1(int n, const double *__restrict__ v, double *__restrict_
 }
 
 __global__ void k_set_gnorm(mopt_rsprfo_state *st, const double *gn) { st[0].gradient_norm = gn[0]; }
+// the tracked TS eigenvector (row *row of Vt; the unit vector when the solver fell back to the identity eigen-system) into a fixed buffer,
+// so that it travels with the other results instead of behind a second synchronisation
+__global__ void __launch_bounds__(256) k_prfo_tsrow(int n, const double *__restrict__ Vt, const int *__restrict__ row, const int *__restrict__ einfo, double *__restrict__ out) {
+    const int r = row[0];
+    if (r < 0) return;
+    const bool ident = (einfo[1] & 1) != 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) out[i] = ident ? (i == r ? 1.0 : 0.0) : Vt[(size_t)r * n + i];
+}
 
 }  // namespace mopt
 
@@ -362,8 +370,7 @@ extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *p
     if (pre_geom && pre_B_g) {
         PH2D(wk.px, pre_geom, nv); PH2D(wk.pg, pre_B_g, nv);
         int rule = params->rule, one = 1;
-        PH2D(wk.rules, &rule, sizeof(int)); PH2D(wk.do_update, &one, sizeof(int));
-        MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        PH2D(wk.rules, &rule, sizeof(int)); PH2D(wk.do_update, &one, sizeof(int));      // (the locals outlive the copies: this block synchronises below)
         // candidate = sym(H + dH) into wk.A; accepted unless max |eig| > 1e6 (rsprfo.py:1236-1250)
         PTRY(mopt_launch_hess_update(ctx, n, 1, wk.rules, wk.do_update, rule == MOPT_RULE_FLOWCHART, wk.x, wk.px, wk.bg, wk.pg, wk.s, wk.y,
                                      wk.u, wk.Hy, wk.yd, wk.Av, wk.coef, wk.info, wk.H, nullptr, wk.A, false, /*guard_sy=*/false));
@@ -413,29 +420,35 @@ extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *p
     PTRY(mopt_launch_backtransform(ctx, n, 1, wk.Vt, wk.coefout, wk.einfo, wk.step));
     MOPT_HIP_TRY(ctx, hipGetLastError());
     int ts_row = -1, bad = 0;
+    std::vector<double> ts_stage;
     {
         // the results come back through the context's pinned staging buffer: none of the copies blocks on pageable memory, one
         // synchronisation (four pageable copies were 70 us of a 0.77 ms call at n = 21); Hessians above 1 MB go straight to the caller
         const bool stage_H = nn <= ((size_t)1 << 20);
-        const size_t o_st = (nv + 255) & ~(size_t)255, o_row = o_st + 256 + ((sizeof(st) + 255) & ~(size_t)255), o_bad = o_row + 256, o_H = o_bad + 256;
+        const size_t o_st = (nv + 255) & ~(size_t)255, o_row = o_st + 256 + ((sizeof(st) + 255) & ~(size_t)255), o_bad = o_row + 256, o_ts = o_bad + 256,
+                     o_H = o_ts + ((nv + 255) & ~(size_t)255);
         char *pin = (char *)mopt_pin_get(ctx, o_H + (stage_H ? nn : 0));
         if (!pin) { ctx->err = "hipHostMalloc failed (staging buffer)"; return MOPT_E_NOMEM; }
         PD2H(pin, wk.step, nv);
         PD2H(pin + o_st, dst.p, sizeof(st));
         PD2H(pin + o_row, dtsrow.p, sizeof(int));
         PD2H(pin + o_bad, wk.einfo + 1, sizeof(int));
+        if (ts_vec_out) {
+            hipLaunchKernelGGL(k_prfo_tsrow, dim3(1), dim3(256), 0, ctx->stream, n, wk.Vt, dtsrow.as<int>(), wk.einfo, dov.as<double>());      // (dov is free behind k_prfo_scalar)
+            PD2H(pin + o_ts, dov.p, nv);
+        }
         if (updated) PD2H(stage_H ? (void *)(pin + o_H) : (void *)H_out, wk.H, nn);
         MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         std::memcpy(step, pin, nv);
         std::memcpy((void *)&st, pin + o_st, sizeof(st));
         std::memcpy(&ts_row, pin + o_row, sizeof(int));
         std::memcpy(&bad, pin + o_bad, sizeof(int));
+        if (ts_vec_out) { ts_stage.resize(n); std::memcpy(ts_stage.data(), pin + o_ts, nv); }
         if (stage_H && updated) std::memcpy(H_out, pin + o_H, nn);
         if (!updated && H_out != hessian) std::memcpy(H_out, hessian, nn);      // (no update: the device copy is the caller's matrix bit for bit)
     }
     if (ts_vec_out && ts_row >= 0) {
-        if (bad & 1) { std::memset(ts_vec_out, 0, nv); ts_vec_out[ts_row] = 1.0; }
-        else { PD2H(ts_vec_out, wk.Vt + (size_t)ts_row * n, nv); MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+        std::memcpy(ts_vec_out, ts_stage.data(), nv);
     }
     st.hess_updated = updated ? 1 : 0;
     *state = st;
