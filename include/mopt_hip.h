@@ -60,6 +60,11 @@ int mopt_ctx_sync(mopt_ctx *ctx);
 /* test hook: `blocks` workgroups holding `lds_bytes` of LDS each stay resident for about `ms` milliseconds on a stream of their
  * own (a co-tenant for the persistent kernels of the eigen-solver); returns immediately. */
 int mopt_debug_occupy(mopt_ctx *ctx, double ms, int lds_bytes, int blocks);
+/* debug mode for workspaces allocated from now on (also MOPT_DEBUG_POISON=1 in the environment): every array of a workspace is filled
+ * with 0xFF bytes (NaN / -1) and separated from its neighbours by guard gaps holding a canary byte; the entry points that end in a
+ * synchronisation (mopt_rsirfo_run, mopt_rsprfo_run, mopt_crsirfo_run, mopt_band_download) then check the gaps and return MOPT_E_STATE,
+ * naming the array in front of a damaged gap.  A read of memory nobody wrote shows up as NaN in the results. */
+int mopt_debug_poison(int enable);
 /* milliseconds spent in the named kernel family since the last reset, measured with HIP
  * events on the ctx stream when timing is enabled (bench.py roofline leg). */
 int mopt_ctx_timing(mopt_ctx *ctx, int enable);
@@ -289,6 +294,14 @@ int mopt_band_upload(mopt_band *band, const double *X, const double *E, const do
  * the reference returns it) on the device; the previous inputs become pre_geom / pre_gradient. */
 int mopt_band_step(mopt_band *band, int optimize_num);
 int mopt_band_download(mopt_band *band, double *newX_angstrom, double *F, double *rfo_step);
+/* Failure bits of the band steps since the host last looked (download, get_state or this call): 4 = the eigen-solver failed for an
+ * image, 8 = the workgroup hand-off of the persistent tridiagonalisation timed out (GPU shared with a long-running kernel).  The bits
+ * are sticky on the device -- a later step does not clear them.  A time-out of the LAST step is repaired here (the flagged images are
+ * solved again with one launch per Householder step, the tail of the step is repeated) and not reported; anything else returns
+ * MOPT_E_NUMERIC.  A caller that enqueues several steps without downloading (bench.py) calls this once behind them.  bits may be NULL. */
+int mopt_band_failures(mopt_band *band, int *bits);
+/* test hook of the debug mode (mopt_debug_poison): writes one byte into the guard gap behind the band's X array */
+int mopt_debug_damage_gap(mopt_band *band);
 /* Same as upload / download with DEVICE pointers (inputs already resident in HBM, e.g. produced by a GPU
  * calculator or staged ahead of time); E_host (I doubles, host) is only read when a step re-creates the
  * optimizer instances (optimize_num == 0) and may be NULL otherwise.  Copies are stream-ordered on the ctx. */

@@ -34,6 +34,18 @@ class RFOOptimizer:
         self._pending_hessians = None         # in-memory counterpart of the tmp_hessian_i.npy side channel
         self._pending_model = None
 
+    def close(self):
+        """Release the device-resident band (Hessians, optimizer state, exchange streams and communicators)."""
+        if self.band is not None:
+            self.band.close()
+            self.band = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def set_apply_ts_opt(self, apply_ts_opt):
         self.apply_ts_opt = apply_ts_opt
 

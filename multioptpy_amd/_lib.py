@@ -34,6 +34,7 @@ def _proto(lib):
     lib.mopt_ctx_sync.argtypes = [vp]
     if hasattr(lib, "mopt_debug_occupy"):
         lib.mopt_debug_occupy.argtypes = [vp, C.c_double, C.c_int, C.c_int]
+    lib.mopt_debug_poison.argtypes = [C.c_int]
     lib.mopt_ctx_timing.argtypes = [vp, C.c_int]
     lib.mopt_ctx_timing_read.argtypes = [vp, C.c_char_p, DP, C.POINTER(C.c_int64)]
     lib.mopt_hess_update.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, DP, DP, DP]
@@ -68,6 +69,7 @@ def _proto(lib):
         lib.mopt_band_download.argtypes = [vp, DP, DP, DP]
         lib.mopt_band_upload_dev.argtypes = [vp, vp, vp, vp, DP]
         lib.mopt_band_download_dev.argtypes = [vp, vp]
+        lib.mopt_band_failures.argtypes = [vp, IP]
     if hasattr(lib, "mopt_crsirfo_run"):
         lib.mopt_constraint_project_hess.argtypes = [vp, C.c_int, DP, C.c_int, DP, C.c_int, DP, C.c_double, C.c_double, DP]
         lib.mopt_crsirfo_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),

@@ -100,6 +100,13 @@ class Band:
     def sync(self):
         check(lib().mopt_ctx_sync(self._ctx), self._ctx)
 
+    def failures(self):
+        """Sticky failure bits of the steps since the last look (4: eigen-solver failure, 8: hand-off time-out); a time-out of the last
+        step is repaired, anything else raises MoptError."""
+        bits = C.c_int(0)
+        check(lib().mopt_band_failures(self._h, C.byref(bits)), self._ctx)
+        return bits.value
+
     def download(self, want_force=False, want_rfo=False):
         newX = np.empty((self.count, self.N, 3))
         F = np.empty((self.I, self.N, 3)) if want_force else None

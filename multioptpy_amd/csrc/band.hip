@@ -236,19 +236,36 @@ using namespace mopt;
 
 #define BTRY(x) do { int rc__ = (x); if (rc__ != MOPT_OK) return rc__; } while (0)
 
+static int band_launch_post(mopt_band *b);
+static int band_check_failures(mopt_band *b, int *bits_out);
+
 int mopt_band_alloc_internal(mopt_band *b) {
     mopt_ctx *ctx = b->ctx;
     if (b->alloc_done) return MOPT_OK;
     const size_t nv = (size_t)b->I * b->n * 8, cv = (size_t)b->count * b->n * 8;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const size_t tot = 7 * al(nv) + 2 * al((size_t)b->I * 8) + 2 * al(cv) + al((size_t)b->count * 8);
+    // (debug mode, pipeline.h: guard gaps between the arrays; the arrays themselves start from zero in either mode -- slots of images a
+    // shard neither owns nor receives are never read, and the whole band reads previous-step arrays only behind have_prev)
+    const bool poison = mopt_debug_poison_on();
+    const size_t gap = poison ? MOPT_CANARY_GAP : 0;
+    struct Item { double **p; size_t bytes; const char *name; size_t off; };
+    double *spareE = nullptr;
+    Item items[] = {{&b->X, nv, "X", 0}, {&b->G, nv, "G", 0}, {&b->pX, nv, "pX", 0}, {&b->pG, nv, "pG", 0}, {&b->F, nv, "F", 0}, {&b->pF, nv, "pF", 0},
+                    {&b->tau, nv, "tau", 0}, {&b->E, (size_t)b->I * 8, "E", 0}, {&spareE, (size_t)b->I * 8, "spareE", 0},
+                    {&b->rfo_delta, cv, "rfo_delta", 0}, {&b->newX, cv, "newX", 0}, {&b->gamma, (size_t)b->count * 8, "gamma", 0}};
+    size_t tot = gap;
+    for (auto &it : items) { it.off = tot; tot += al(it.bytes) + gap; }
     MOPT_HIP_TRY(ctx, hipMalloc(&b->block, tot));
-    MOPT_HIP_TRY(ctx, hipMemsetAsync(b->block, 0, tot, ctx->stream));
-    char *p = (char *)b->block;
-    auto take = [&](size_t x) { void *r = p; p += al(x); return (double *)r; };
-    b->X = take(nv); b->G = take(nv); b->pX = take(nv); b->pG = take(nv); b->F = take(nv); b->pF = take(nv); b->tau = take(nv);
-    b->E = take((size_t)b->I * 8); take((size_t)b->I * 8);
-    b->rfo_delta = take(cv); b->newX = take(cv); b->gamma = take((size_t)b->count * 8);
+    MOPT_HIP_TRY(ctx, hipMemsetAsync(b->block, poison ? MOPT_CANARY_BYTE : 0, tot, ctx->stream));
+    b->gaps.clear(); b->gap_names.clear();
+    if (poison) { b->gaps.emplace_back(0, gap); b->gap_names.push_back("(start of block)"); }
+    for (auto &it : items) {
+        *it.p = (double *)((char *)b->block + it.off);
+        if (poison) {
+            MOPT_HIP_TRY(ctx, hipMemsetAsync(*it.p, 0, it.bytes, ctx->stream));
+            b->gaps.emplace_back(it.off + it.bytes, al(it.bytes) - it.bytes + gap); b->gap_names.push_back(it.name);
+        }
+    }
     BTRY(b->wk.alloc(ctx, b->n, b->count, true, false, false));
     MOPT_HIP_TRY(ctx, hipMalloc(&b->dots, MOPT_MAX_RANKS * sizeof(double)));
     MOPT_HIP_TRY(ctx, hipMemsetAsync(b->dots, 0, MOPT_MAX_RANKS * sizeof(double), ctx->stream));
@@ -282,6 +299,8 @@ extern "C" int mopt_band_create(mopt_ctx *ctx, int I, int N, mopt_band **out) {
 
 extern "C" int mopt_band_destroy(mopt_band *b) {
     if (!b) return MOPT_E_ARG;
+    // (a band that is destroyed before its communicator leaves the group first: mopt_comm_destroy must not find a dangling pointer)
+    if (b->comm) { mopt_comm_detach_band(b->comm, b); b->comm = nullptr; }
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     if (b->cst) { hipStreamSynchronize(b->cst); hipStreamDestroy(b->cst); }
@@ -371,6 +390,7 @@ extern "C" int mopt_band_get_state(mopt_band *b, int image, mopt_rsirfo_state *o
     const int loc = band_local(b, image);
     if (loc < 0) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
+    BTRY(band_check_failures(b, nullptr));
     MOPT_HIP_TRY(ctx, hipMemcpyAsync(out, b->wk.states + loc, sizeof(mopt_rsirfo_state), hipMemcpyDeviceToHost, ctx->stream));
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     if (out->jacobi_sweeps < 0) { ctx->err = "mopt_band_get_state: the eigen-solver failed for this image"; return MOPT_E_NUMERIC; }
@@ -482,6 +502,72 @@ int mopt_band_step_phase_a(mopt_band *b, int optimize_num) {
     return MOPT_OK;
 }
 
+// step limit, TR_calc, FIRE, blend of the last step (idempotent: reads the step's inputs and wk.step, writes rfo_delta and newX)
+static int band_launch_post(mopt_band *b) {
+    mopt_ctx *ctx = b->ctx;
+    const bool sharded = (b->comm != nullptr);
+    mopt_scope sc(ctx, "neb_post", 1);
+    hipLaunchKernelGGL(k_neb_post, dim3(b->count), dim3(512), (size_t)2 * b->n * 8, ctx->stream, b->I, b->N, b->first, b->last_optimize_num,
+                       b->last_have_prev ? 1 : 0, b->ratio, b->fix_init, b->fix_end, b->X, b->G, b->F, b->pF, b->wk.step, b->rfo_delta, b->newX,
+                       sharded ? (const double *)b->dots : (const double *)nullptr, sharded ? mopt_comm_nranks(b->comm) : 0);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}
+
+// Failure words of the steps since the host last looked.  A hand-off time-out (bit 8) of the LAST step is repaired here: the flagged images
+// are solved again with one launch per Householder step and the tail of the step is repeated (the optimizer state of a flagged image was
+// left untouched by k_rfo_scalar).  A failure of an EARLIER step that nobody looked at cannot be repaired any more (its inputs are gone)
+// and is reported.  bits_out (may be null): the sticky bits found.
+static int band_check_failures(mopt_band *b, int *bits_out) {
+    mopt_ctx *ctx = b->ctx;
+    if (bits_out) *bits_out = 0;
+    if (!b->stepped) return MOPT_OK;
+    int sticky = 0;
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(&sticky, b->wk.sticky, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const int nsteps = b->steps_since_check;
+    b->steps_since_check = 0;
+    if (bits_out) *bits_out = sticky;
+    if (!sticky) return MOPT_OK;
+    MOPT_HIP_TRY(ctx, hipMemsetAsync(b->wk.sticky, 0, sizeof(int), ctx->stream));
+    if ((sticky & 8) && nsteps <= 1) {
+        RsirfoWork &wk = b->wk;
+        const int n = b->n, first = b->first;
+        double *sx = wk.x, *sbg = wk.bg, *sg = wk.g, *spx = wk.px, *spg = wk.pg;
+        wk.x = b->X + (size_t)first * n; wk.bg = b->G + (size_t)first * n; wk.g = wk.bg;
+        wk.px = b->pX + (size_t)first * n; wk.pg = b->pG + (size_t)first * n;
+        int nre = 0;
+        int rc = mopt_rsirfo_retry_timeouts(ctx, wk, n, b->count, wk.H, b->last_have_coef, &nre);
+        wk.x = sx; wk.bg = sbg; wk.g = sg; wk.px = spx; wk.pg = spg;
+        if (rc != MOPT_OK) return rc;
+        BTRY(band_launch_post(b));
+        int again = 0;
+        MOPT_HIP_TRY(ctx, hipMemcpyAsync(&again, b->wk.sticky, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(b->wk.sticky, 0, sizeof(int), ctx->stream));
+        if (bits_out) *bits_out = again;
+        if (!again) return MOPT_OK;
+        sticky = again;
+    }
+    ctx->err = (sticky & 8) ? "band step: the workgroup hand-off of the tridiagonalisation timed out in a step that can no longer be repeated (GPU shared with a long-running kernel)"
+                            : "band step: the eigen-solver failed for an image of this shard";
+    return MOPT_E_NUMERIC;
+}
+
+// test hook of the debug mode: writes one byte into the guard gap behind the band's X array
+extern "C" int mopt_debug_damage_gap(mopt_band *b) {
+    if (!b || b->gaps.size() < 2) return MOPT_E_STATE;
+    hipSetDevice(b->ctx->device);
+    MOPT_HIP_TRY(b->ctx, hipMemset((char *)b->block + b->gaps[1].first + 3, 0, 1));
+    return MOPT_OK;
+}
+
+extern "C" int mopt_band_failures(mopt_band *b, int *bits) {
+    if (!b) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    return band_check_failures(b, bits);
+}
+
 int mopt_band_step_phase_b(mopt_band *b, int optimize_num) {
     mopt_ctx *ctx = b->ctx;
     hipSetDevice(ctx->device);
@@ -508,15 +594,11 @@ int mopt_band_step_phase_b(mopt_band *b, int optimize_num) {
     b->stepped = true;
     wk.x = sx; wk.bg = sbg; wk.g = sg; wk.px = spx; wk.pg = spg;
     if (rc != MOPT_OK) return rc;
+    b->last_optimize_num = optimize_num; b->last_have_prev = have_prev; b->last_have_coef = fused || have_prev;
+    ++b->steps_since_check;
     // 4.-7. step limit, TR_calc, FIRE, blend
-    {
-        if (sharded) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, b->ev_dot_done, 0));      // every rank's partial sum has arrived
-        mopt_scope sc(ctx, "neb_post", 1);
-        hipLaunchKernelGGL(k_neb_post, dim3(count), dim3(512), (size_t)2 * n * 8, ctx->stream, I, N, first, optimize_num,
-                           have_prev ? 1 : 0, b->ratio, b->fix_init, b->fix_end, b->X, b->G, b->F, b->pF, wk.step, b->rfo_delta, b->newX,
-                           sharded ? (const double *)b->dots : (const double *)nullptr, sharded ? mopt_comm_nranks(b->comm) : 0);
-    }
-    MOPT_HIP_TRY(ctx, hipGetLastError());
+    if (sharded) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, b->ev_dot_done, 0));      // every rank's partial sum has arrived
+    BTRY(band_launch_post(b));
     b->have_prev = true;
     b->halo_done = false;
     return MOPT_OK;
@@ -590,6 +672,7 @@ extern "C" int mopt_band_download(mopt_band *b, double *newX_angstrom, double *F
     mopt_ctx *ctx = b->ctx;
     hipSetDevice(ctx->device);
     const size_t cv = (size_t)b->count * b->n * 8;
+    BTRY(band_check_failures(b, nullptr));                   // (repairs a hand-off time-out of the last step, reports anything else)
     if (newX_angstrom) MOPT_HIP_TRY(ctx, hipMemcpyAsync(newX_angstrom, b->newX, cv, hipMemcpyDeviceToHost, ctx->stream));
     if (F) MOPT_HIP_TRY(ctx, hipMemcpyAsync(F, b->F, (size_t)b->I * b->n * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (rfo_step) MOPT_HIP_TRY(ctx, hipMemcpyAsync(rfo_step, b->rfo_delta, cv, hipMemcpyDeviceToHost, ctx->stream));
@@ -598,6 +681,10 @@ extern "C" int mopt_band_download(mopt_band *b, double *newX_angstrom, double *F
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < b->count; ++i)
         if (einfo[2 * i + 1] & 4) { ctx->err = "mopt_band_download: the eigen-solver failed for an image of this shard"; return MOPT_E_NUMERIC; }
+    if (!b->gaps.empty()) {                                  // debug mode: guard gaps of the band's arrays and of its RSIRFO workspace
+        BTRY(mopt_check_gaps(ctx, b->block, b->gaps, b->gap_names, "band arrays"));
+        BTRY(b->wk.check_canaries());
+    }
     return MOPT_OK;
 }
 

@@ -130,7 +130,12 @@ static int create_group(int kind, int nranks, mopt_ctx *const *ctxs, mopt_comm *
     }
     for (int r = 0; r < nranks; ++r) {
         mopt_comm *c = new (std::nothrow) mopt_comm();
-        if (!c) return MOPT_E_NOMEM;
+        if (!c) {                                            // unwind: the handles created so far, every RCCL communicator, the group
+            for (int q = 0; q < r; ++q) { delete outs[q]; outs[q] = nullptr; }
+            if (kind == MOPT_COMM_RCCL) for (int q = 0; q < nranks; ++q) if (comms[q]) { hipSetDevice(ctxs[q]->device); g_rccl.CommDestroy(comms[q]); }
+            delete g;
+            return MOPT_E_NOMEM;
+        }
         c->grp = g; c->rank = r; c->ctx = ctxs[r]; c->nccl = comms[r];
         outs[r] = c;
     }
@@ -139,6 +144,12 @@ static int create_group(int kind, int nranks, mopt_ctx *const *ctxs, mopt_comm *
 
 extern "C" int mopt_comm_create_rccl_all(int nranks, mopt_ctx *const *ctxs, mopt_comm **outs) { return create_group(MOPT_COMM_RCCL, nranks, ctxs, outs); }
 extern "C" int mopt_comm_create_peer(int nranks, mopt_ctx *const *ctxs, mopt_comm **outs) { return create_group(MOPT_COMM_PEER, nranks, ctxs, outs); }
+
+// the band leaves its group (mopt_band_destroy): the slot is cleared, nothing of the band is touched
+void mopt_comm_detach_band(mopt_comm *c, mopt_band *b) {
+    if (!c || !c->grp) return;
+    if (c->rank < (int)c->grp->bands.size() && c->grp->bands[c->rank] == b) c->grp->bands[c->rank] = nullptr;
+}
 
 extern "C" int mopt_comm_destroy(mopt_comm *c) {
     if (!c) return MOPT_E_ARG;
@@ -176,7 +187,12 @@ static int halo_rccl(int nb, mopt_band *const *bands) {
     bool any = false;
     for (int k = 0; k < nb; ++k) any = any || bands[k]->comm->grp->nranks > 1;
     mopt_ctx *ctx0 = bands[0]->ctx;
-    if (any) CTRY(ctx0, g_rccl.GroupStart());
+    if (!any) return MOPT_OK;
+    // Two groups on the same communicator and stream, one behind the other: (1) the point-to-point boundary rows, (2) the energy
+    // all-gather.  RCCL documents grouped send/recv pairs and grouped collectives; a group that MIXES both kinds on one
+    // communicator is not a documented use, so they are kept apart (stream order makes (2) follow (1); the cost is one more
+    // enqueue of a < 1 KB collective off the critical path).
+    CTRY(ctx0, g_rccl.GroupStart());
     for (int k = 0; k < nb; ++k) {
         mopt_band *b = bands[k];
         mopt_comm *c = b->comm;
@@ -196,9 +212,17 @@ static int halo_rccl(int nb, mopt_band *const *bands) {
             CTRY(b->ctx, g_rccl.Recv(b->X + hi + n, n, ncclDouble, r + 1, c->nccl, b->cst));
             CTRY(b->ctx, g_rccl.Recv(b->G + hi + n, n, ncclDouble, r + 1, c->nccl, b->cst));
         }
+    }
+    CTRY(ctx0, g_rccl.GroupEnd());
+    CTRY(ctx0, g_rccl.GroupStart());
+    for (int k = 0; k < nb; ++k) {
+        mopt_band *b = bands[k];
+        mopt_comm *c = b->comm;
+        if (c->grp->nranks == 1) continue;
+        hipSetDevice(b->ctx->device);
         CTRY(b->ctx, g_rccl.AllGather(b->E + b->first, b->E, (size_t)b->count, ncclDouble, c->nccl, b->cst));      // (in place)
     }
-    if (any) CTRY(ctx0, g_rccl.GroupEnd());
+    CTRY(ctx0, g_rccl.GroupEnd());
     return MOPT_OK;
 }
 

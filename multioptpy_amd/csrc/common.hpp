@@ -185,6 +185,7 @@ struct mopt_ctx {
     std::map<std::string, mopt_timer> timers;
     int lds_limit = 65536;
     int num_cu = 256;
+    long long n_retries = 0;                 // images solved again after a hand-off time-out (mopt_ctx_timing_read family "tri_retries")
     bool tri_no_persist = false;             // eigen-solver: take the launch-per-step tridiagonalisation (retry after a hand-off time-out)
     // early start of the leading block (k_early.hip): staging + flags (grow-only), and the D array known to hold the sentinel
     void *early_buf = nullptr; size_t early_bytes = 0; const void *early_clean = nullptr;

@@ -118,9 +118,34 @@ extern "C" int mopt_constraint_project_hess(mopt_ctx *ctx, int n, const double *
 
 // U: n x m (row-major, orthonormal columns: the null space of the constraints).  Everything else as mopt_rsirfo_run with batch 1;
 // B_g is the full-space gradient (after the caller's gradient transport, if any).
+static int crsirfo_run_once(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
+                            const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                            const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym);
+
 extern "C" int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
                                 const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
                                 const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym) {
+    if (!ctx || !state) return MOPT_E_ARG;
+    // (a hand-off time-out -- jacobi_sweeps = -2, k_rfo_scalar -- is repeated once with one launch per Householder step; the outputs
+    // may alias the input Hessian: keep a copy)
+    const mopt_rsirfo_state st0 = *state;
+    std::vector<double> hkeep;
+    if (hessian && n > 0 && (H_inplace == hessian || H_sym == hessian)) hkeep.assign(hessian, hessian + (size_t)n * n);
+    int rc = crsirfo_run_once(ctx, n, m, params, state, hessian, bias_hessian, geom, B_g, g, pre_geom, pre_g, B_e, U, step, H_inplace, H_sym);
+    if (rc == MOPT_E_NUMERIC && state->jacobi_sweeps == -2) {
+        *state = st0;
+        const bool saved = ctx->tri_no_persist;
+        ctx->tri_no_persist = true;
+        rc = crsirfo_run_once(ctx, n, m, params, state, hkeep.empty() ? hessian : hkeep.data(), bias_hessian, geom, B_g, g, pre_geom, pre_g, B_e, U, step,
+                              H_inplace, H_sym);
+        ctx->tri_no_persist = saved;
+    }
+    return rc;
+}
+
+static int crsirfo_run_once(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
+                            const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                            const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym) {
     using namespace mopt;
     if (!ctx) return MOPT_E_ARG;
     if (n < 1 || n > MOPT_MAX_N || m < 1 || m > n || !params || !state || !geom || !B_g || !B_e || !U || !step) { ctx->err = "mopt_crsirfo_run: bad arguments"; return MOPT_E_ARG; }
@@ -172,6 +197,7 @@ extern "C" int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_p
     if (H_inplace) CD2H(ctx, H_inplace, upd ? wk.Hinpl : wk.H, nn);
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     MOPT_HIP_TRY(ctx, hipGetLastError());
+    if (mopt_debug_poison_on()) { CTRY_(wk.check_canaries()); CTRY_(ws.check_canaries()); }
     if (state->jacobi_sweeps < 0) { ctx->err = "mopt_crsirfo_run: the eigen-solver failed"; return MOPT_E_NUMERIC; }
     return MOPT_OK;
 }

@@ -333,11 +333,43 @@ struct DB {
 static int g_prfo_attr = 0;
 void *mopt_pin_get(mopt_ctx *ctx, size_t bytes);      // pinned staging of the context (mopt_abi.hip)
 
+static int rsprfo_run_once(mopt_ctx *ctx, int n, const mopt_rsprfo_params *params, mopt_rsprfo_state *state,
+                           const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
+                           const double *pre_geom, const double *pre_B_g, double B_e, const double *prev_gradient,
+                           const double *prev_move_vector, double pre_move_norm, const double *ts_vec, double *step,
+                           double *H_out, double *ts_vec_out, bool *timed_out);
+
 extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *params, mopt_rsprfo_state *state,
                                const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
                                const double *pre_geom, const double *pre_B_g, double B_e, const double *prev_gradient,
                                const double *prev_move_vector, double pre_move_norm, const double *ts_vec, double *step,
                                double *H_out, double *ts_vec_out) {
+    if (!ctx || !state) return MOPT_E_ARG;
+    // A hand-off time-out of the persistent tridiagonalisation (GPU shared with a long-running kernel) is not a numerical failure: the
+    // call is repeated once from the caller's inputs with one launch per Householder step (H_out may alias `hessian`: keep a copy).
+    const mopt_rsprfo_state st0 = *state;
+    std::vector<double> hkeep;
+    if (H_out == hessian && hessian && n > 0) hkeep.assign(hessian, hessian + (size_t)n * n);
+    bool timed_out = false;
+    int rc = rsprfo_run_once(ctx, n, params, state, hessian, bias_hessian, geom, B_g, pre_geom, pre_B_g, B_e, prev_gradient, prev_move_vector,
+                             pre_move_norm, ts_vec, step, H_out, ts_vec_out, &timed_out);
+    if (rc == MOPT_OK && timed_out) {
+        *state = st0;
+        const bool saved = ctx->tri_no_persist;
+        ctx->tri_no_persist = true;
+        rc = rsprfo_run_once(ctx, n, params, state, hkeep.empty() ? hessian : hkeep.data(), bias_hessian, geom, B_g, pre_geom, pre_B_g, B_e, prev_gradient,
+                             prev_move_vector, pre_move_norm, ts_vec, step, H_out, ts_vec_out, &timed_out);
+        ctx->tri_no_persist = saved;
+    }
+    return rc;
+}
+
+static int rsprfo_run_once(mopt_ctx *ctx, int n, const mopt_rsprfo_params *params, mopt_rsprfo_state *state,
+                           const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
+                           const double *pre_geom, const double *pre_B_g, double B_e, const double *prev_gradient,
+                           const double *prev_move_vector, double pre_move_norm, const double *ts_vec, double *step,
+                           double *H_out, double *ts_vec_out, bool *timed_out) {
+    *timed_out = false;
     if (!ctx) return MOPT_E_ARG;
     if (n < 3 || n % 3 != 0 || n > MOPT_MAX_N) { ctx->err = "mopt_rsprfo_run: bad n"; return MOPT_E_ARG; }
     if (!params || !state || !geom || !B_g || !step || !H_out) { ctx->err = "mopt_rsprfo_run: null argument"; return MOPT_E_ARG; }
@@ -452,5 +484,7 @@ extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *p
     }
     st.hess_updated = updated ? 1 : 0;
     *state = st;
+    *timed_out = (bad & 8) != 0;
+    if (mopt_debug_poison_on()) PTRY(wk.check_canaries());
     return MOPT_OK;
 }

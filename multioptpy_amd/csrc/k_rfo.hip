@@ -84,6 +84,16 @@ __global__ void __launch_bounds__(192) k_rfo_scalar(int n, const mopt_rsirfo_par
     const bool bad_eig = (einfo[2 * b + 1] & 1) != 0;
     const double *gt_all = gt_all_ + (size_t)b * n;
     double *coef_out = coef_out_ + (size_t)b * n;
+    if (einfo[2 * b + 1] & 8) {
+        // hand-off time-out of the persistent tridiagonalisation (GPU shared with a long-running kernel): not a numerical event.  The
+        // optimizer state of this image stays as it was, so the host can solve the image again (mopt_rsirfo_retry_timeouts) and run this
+        // stage for it a second time; the step is zero until then.  jacobi_sweeps = -2 tells the two kinds of failure apart.
+        if (wid == 0) {
+            for (int k = lane; k < n; k += WAVE) coef_out[k] = 0.0;
+            if (lane == 0) states[b].jacobi_sweeps = -2;
+        }
+        return;
+    }
 
     for (int k = lane; k < n; k += WAVE) {
         if (bad_eig) { w0[k] = 1.0; vidx[k] = k; }

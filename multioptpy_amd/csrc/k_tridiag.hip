@@ -2077,7 +2077,7 @@ __global__ void __launch_bounds__(64) k_tri_invit(int n, const double *__restric
 
 // ascending sort of WT -> W, perm (same contract as k_jac_finalize); dynamic LDS npow2 * 12 bytes
 __global__ void __launch_bounds__(1024) k_tri_sort(int n, int npow2, const double *__restrict__ WT_, const int *__restrict__ fail_,
-                                                  double *__restrict__ W, int *__restrict__ perm, int *__restrict__ info, double *clrD, double *clrE) {
+                                                  double *__restrict__ W, int *__restrict__ perm, int *__restrict__ info, double *clrD, double *clrE, int *__restrict__ sticky) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double *key = sm;
     int *idx = (int *)(sm + npow2);
@@ -2116,7 +2116,12 @@ __global__ void __launch_bounds__(1024) k_tri_sort(int n, int npow2, const doubl
     // persistent tridiagonalisation (GPU shared with a long-running kernel), not a numerical one
     // Non-finite eigenvalues (a NaN / Inf Hessian, rsirfo.py:365-372: "common for linear molecules and poor initial guesses") are not
     // a solver failure: the consumers replace such an eigen-system by (w = 1, V = I) and continue as steepest descent, as the reference.
-    if (threadIdx.x == 0) { const int f = fail_[b]; info[2 * b] = 0; info[2 * b + 1] = bad ? 1 : ((f ? 4 : 0) | (f >= TRI_FAIL_TIMEOUT ? 8 : 0)); }
+    if (threadIdx.x == 0) {
+        const int f = fail_[b];
+        const int word = bad ? 1 : ((f ? 4 : 0) | (f >= TRI_FAIL_TIMEOUT ? 8 : 0));
+        info[2 * b] = 0; info[2 * b + 1] = word;
+        if (sticky && (word & 12)) atomicOr(sticky, word & 12);      // (never cleared on the device: a failed step stays visible to the host whatever follows it)
+    }
     // last reader of D and E in a solve: leave the all-ones sentinel k_tri_early (k_early.hip) expects in front of the next solve
     if (clrD) for (int i = threadIdx.x; i < n; i += blockDim.x) { ((unsigned long long *)clrD)[(size_t)b * n + i] = ~0ull; ((unsigned long long *)clrE)[(size_t)b * n + i] = ~0ull; }
 }
@@ -2162,7 +2167,7 @@ int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double
 // d_Z2: batch*(n*n + MOPT_TRI_T_DOUBLES(n)) doubles (scratch copy of the eigenvectors for the cluster orthogonalisation, then the T factors of the blocked back-transformation).  d_bstart, d_bend: batch*n ints; d_cstart: 2*batch*n ints (tight and loose cluster tables); d_ncl: 2*batch ints; d_fail: batch ints.
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook) {
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook, int *d_sticky) {
     using namespace mopt;
     if (n < 3) { ctx->err = "tridiagonal eigen-solver needs n >= 3"; return MOPT_E_ARG; }
     if (hook) hook->used = false;
@@ -2177,7 +2182,27 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tridiag, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
     const bool multi = !(tri_env("MOPT_TRI_SINGLE")) && n >= 32;
     const bool no_persist = ctx->tri_no_persist || tri_env("MOPT_TRI_NOPERSIST");
-    const bool pre_cleared = hook && hook->pre_cleared;      // (failure flags and exchange area zeroed by the caller's last kernel)
+    bool pre_cleared = hook && hook->pre_cleared;            // (failure flags and exchange area zeroed by the caller's last kernel)
+    if (mopt_debug_poison_on()) {
+        // debug mode: every array this solve is expected to (re)write is poisoned at its start, so an entry that a kernel leaves unwritten
+        // cannot hide behind the previous solve's (finite, plausible) value -- it reaches the results as NaN / index -1
+        const size_t nvb = (size_t)batch * n;
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_WT, 0xFF, nvb * 8, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_W, 0xFF, nvb * 8, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_onenrm, 0xFF, nvb * 8, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_TAU, 0xFF, nvb * 8, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_perm, 0xFF, nvb * 4, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_bstart, 0xFF, nvb * 4, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_bend, 0xFF, nvb * 4, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_cstart, 0xFF, 2 * nvb * 4, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_ncl, 0xFF, (size_t)2 * batch * 4, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_info, 0xFF, (size_t)2 * batch * 4, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_Vt, 0xFF, nvb * n * 8, ctx->stream));
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(d_Z2, 0xFF, (size_t)batch * ((size_t)n * n + MOPT_TRI_T_DOUBLES(n)) * 8, ctx->stream));
+        if (hook && hook->vout) MOPT_HIP_TRY(ctx, hipMemsetAsync(hook->vout, 0xFF, nvb * n * 8, ctx->stream));
+        if (hook && hook->gq) MOPT_HIP_TRY(ctx, hipMemsetAsync(hook->gq, 0xFF, nvb * 8, ctx->stream));
+        pre_cleared = false;                                 // (the caller's zeroing of the exchange area has just been overwritten)
+    }
     if (!pre_cleared) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 0, (size_t)batch * sizeof(int), ctx->stream));
     // persistent LDS-resident variant: G workgroups per matrix with rows_cap * n doubles of LDS each
     int G = 8;
@@ -2608,7 +2633,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         mopt_scope sc(ctx, "eigh_final", 1);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
-        hipLaunchKernelGGL(k_tri_sort, dim3(batch), dim3(n <= 256 ? 256 : n <= 512 ? 512 : 1024), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_WT, d_fail, d_W, d_perm, d_info, clr_D, clr_E);
+        hipLaunchKernelGGL(k_tri_sort, dim3(batch), dim3(n <= 256 ? 256 : n <= 512 ? 512 : 1024), (size_t)np2 * 12 + 16, ctx->stream, n, np2, d_WT, d_fail, d_W, d_perm, d_info, clr_D, clr_E, d_sticky);
     };
     if (use_hook) {
         // the caller's scalar stage next to V = Q Z: its inputs are the eigenvalues and Z^T (Q^T g)

@@ -187,6 +187,11 @@ extern "C" int mopt_ctx_timing_read(mopt_ctx *ctx, const char *family, double *m
         if (launches) *launches = 0;
         return MOPT_OK;
     }
+    if (std::string(family) == "tri_retries") {              // (not a timer: images solved again after a hand-off time-out, since the context exists)
+        if (ms) *ms = 0.0;
+        if (launches) *launches = ctx->n_retries;
+        return MOPT_OK;
+    }
     auto it = ctx->timers.find(family);
     double tot = 0.0; int64_t nl = 0;
     if (it != ctx->timers.end()) {
@@ -510,6 +515,19 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
     if (H_sym) D2H(ctx, stage_H ? (void *)(pin + hs_off) : (void *)H_sym, wk.H, nn);
     if (H_inplace) D2H(ctx, stage_H ? (void *)(pin + hi_off) : (void *)H_inplace, any_upd ? wk.Hinpl : wk.H, nn);
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    {
+        // a hand-off time-out of the persistent tridiagonalisation (jacobi_sweeps = -2: the GPU is shared with a long-running kernel) is
+        // not a numerical failure: those geometries are solved again with one launch per Householder step
+        bool timed_out = false;
+        for (int b = 0; b < batch; ++b) timed_out = timed_out || ((const mopt_rsirfo_state *)pout)[b].jacobi_sweeps == -2;
+        if (timed_out) {
+            int nre = 0;
+            TRY(mopt_rsirfo_retry_timeouts(ctx, wk, n, batch, wk.H, any_upd, &nre));
+            D2H(ctx, pout, wk.states, out_bytes);
+            MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    if (mopt_debug_poison_on()) TRY(wk.check_canaries());
     std::memcpy(state, pout, batch * sizeof(mopt_rsirfo_state));
     std::memcpy(step, pout + ((char *)wk.step - (char *)wk.states), nv);
     if (stage_H && H_sym) std::memcpy(H_sym, pin + hs_off, nn);

@@ -28,13 +28,26 @@ struct RsirfoWork {
     double *gp = nullptr, *Q = nullptr, *W6 = nullptr, *eigw = nullptr, *gt_all = nullptr, *coefout = nullptr, *step = nullptr;
     double *be = nullptr, *sigma = nullptr, *info = nullptr;
     int *perm = nullptr, *einfo = nullptr, *rotcount = nullptr, *rules = nullptr, *do_update = nullptr;
+    int *sticky = nullptr;        // [1] failure bits (4: solver failure, 8: hand-off time-out) OR-ed by every solve on this workspace, cleared by the host only
     mopt::UpdateCoef *coef = nullptr;
     mopt_rsirfo_params *params = nullptr;
     mopt_rsirfo_state *states = nullptr;
     TriScratch tri = {};
+    // debug mode (mopt_debug_poison): every array of the block is preceded and followed by a guard gap filled with MOPT_CANARY_BYTE and is
+    // itself filled with 0xFF bytes (a NaN as a double, -1 as an int) -- an out-of-bounds write damages a gap, a read of memory nobody
+    // wrote shows up as NaN in the results.  check_canaries returns MOPT_E_STATE and names the array in front of the first damaged gap.
+    size_t total_bytes = 0;
+    std::vector<std::pair<size_t, size_t>> gaps;             // (offset, bytes) of the guard gaps inside `block`
+    std::vector<const char *> gap_names;                     // array in front of each gap
     int alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool with_bias, bool with_inplace);
+    int check_canaries();
     ~RsirfoWork();
 };
+#define MOPT_CANARY_BYTE 0xA5
+#define MOPT_CANARY_GAP 1024     /* bytes; a multiple of the 256-byte array alignment */
+bool mopt_debug_poison_on();
+// guard-gap check of an arbitrary device block (band.hip's own block uses it too)
+int mopt_check_gaps(mopt_ctx *ctx, const void *block, const std::vector<std::pair<size_t, size_t>> &gaps, const std::vector<const char *> &names, const char *what);
 
 // Band path, fused form (k_fused.hip): Ayala term gamma t t^T, quasi-Newton update and TR/rot projection in three launches.
 namespace mopt { struct FusedBand { const double *gamma; const double *tau; int first; int upd_all; bool clear_for_eigh; }; }
@@ -47,6 +60,11 @@ int mopt_launch_fused_update_project(mopt_ctx *ctx, RsirfoWork &wk, int n, int b
 // applied here and not by the caller.
 int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
                          double *d_Hinpl, double *d_Hsym, bool warm_eigh = false, const mopt::FusedBand *fb = nullptr);
+
+// Images whose eigen-solve reported a hand-off time-out of the persistent tridiagonalisation (einfo bit 8; k_rfo_scalar leaves their
+// state untouched): A is formed again from the (already updated) Hessian and the image is solved with one launch per Householder
+// step, then the RS-I-RFO stage runs for it.  Synchronises the stream.  wk.x / bg / ... must point at the step's inputs.
+int mopt_rsirfo_retry_timeouts(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, const double *d_Hsym, bool have_coef, int *nretried);
 
 // launchers (defined next to their kernels)
 int mopt_launch_hess_update(mopt_ctx *ctx, int n, int batch, const int *d_rules, const int *d_do_update, bool any_flowchart,
@@ -97,7 +115,7 @@ bool mopt_apply_qt_supported(int n);
 int mopt_launch_apply_qt(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_A, const double *d_T, const double *d_in, double *d_out);
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook = nullptr);
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook = nullptr, int *d_sticky = nullptr);
 // algorithm switch: 0 = block Jacobi (k_eigh.hip), 1 = tridiagonal reduction route (k_tridiag.hip); env MOPT_EIGH_ALGO overrides
 int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, bool preserve_A = true, EighRfoHook *hook = nullptr);
 int mopt_eigh_algo(int n);   // 1 = reduction route (k_tridiag.hip), 0 = one-sided Jacobi (k_eigh.hip)

@@ -94,6 +94,13 @@ class Comm:
             lib().mopt_comm_destroy(self._h)
             self._h = None
 
+    def __del__(self):
+        # (either order of band / communicator teardown is safe in the library: each side detaches itself from the other)
+        try:
+            self.close()
+        except Exception:
+            pass
+
 
 def _create_group(fn, devices):
     ctxs = [_lib.ctx(d) for d in devices]
@@ -178,6 +185,18 @@ class ShardedBand:
         for c in self.comms:
             c.close()
         self.bands, self.comms = [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def failures(self):
+        bits = 0
+        for b in self.bands:
+            bits |= b.failures()
+        return bits
 
     def _owner(self, image):
         for b in self.bands:
