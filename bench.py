@@ -209,12 +209,15 @@ def main():
     dev = torch.device("cuda", local)
     comm = rccl_comm_for_process(local) if world > 1 else None      # RCCL communicator of the library, id broadcast by torch.distributed
 
+    checks = {}
+
     def measure(hess_init, W, K, want_families):
         """W warm-up + K timed band steps of the workload; returns (ms per step, family timings, trajectory, Hessians, sweeps)."""
         hess0 = lj_hessians(cases.band(I, N)) if hess_init == "exact" else None
         # ---- inputs for every step, staged in HBM (untimed)
-        traj = make_trajectory(I, N, W + K, local, hess0)
-        staged = [(torch.from_numpy(X).to(dev), torch.from_numpy(E).to(dev), torch.from_numpy(G).to(dev)) for X, E, G in traj]
+        # (one step more than is timed: traj[W + K] holds the geometry the last timed step must produce -- the check below)
+        traj = make_trajectory(I, N, W + K + 1, local, hess0)
+        staged = [(torch.from_numpy(X).to(dev), torch.from_numpy(E).to(dev), torch.from_numpy(G).to(dev)) for X, E, G in traj[:W + K]]
         torch.cuda.synchronize()
 
         def run(band, timing=False):
@@ -258,10 +261,22 @@ def main():
 
         band = fresh()
         elapsed = run(band)
+        # ---- outside the timed region: (1) no step of the timed loop may have failed (the failure word is sticky on the device; a
+        # hand-off time-out or a solver failure in ANY of the K steps raises here instead of being timed as a valid step);
+        # (2) the geometry the last timed step produced on this rank's images equals the whole-band trajectory (computed above on this
+        # rank's GPU by the unsharded band): for N > 1 this is the proof that the RCCL exchange delivered the right rows
+        bits = band.failures()
+        if bits:
+            raise SystemExit(f"bench: a timed band step failed (failure bits {bits})")
+        got = band.download() / cases.BOHR2ANG
+        dev_shard = float(np.abs(got - traj[W + K][0][first:first + count]).max())
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            t = torch.tensor([elapsed, dev_shard], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed, dev_shard = float(t[0].item()), float(t[1].item())
+        if not dev_shard < 1e-10:
+            raise SystemExit(f"bench: the sharded band deviates from the whole-band trajectory by {dev_shard} bohr after the last timed step")
+        checks[hess_init] = dev_shard
         sweeps = [band.get_state(first + j).jacobi_sweeps for j in range(count)]
         band.close()
         fam = {}
@@ -270,6 +285,8 @@ def main():
             # every rank runs it -- run() contains barriers -- but only rank 0 records and reports)
             b2 = fresh()
             run(b2, timing=(rank == 0))
+            if b2.failures():
+                raise SystemExit("bench: a band step of the family-timing pass failed")
             if rank == 0:
                 if os.environ.get("MOPT_TIMELINE"):
                     b2.timing_read("timeline")
@@ -358,6 +375,11 @@ def main():
                                    "block-Bofill/FSB update + TR/rot projection + eigh + RS-I-RFO + BNEB force + TR/FIRE blend",
                        "images": I, "atoms": N, "images_per_gpu": count, "parallelism": f"image-sharded x{world}",
                        "hessian_init": args.hessian_init,
+                       "window": f"band steps {W}..{W + K - 1} of a run started from {args.hessian_init} Hessians"
+                                 + (" (identity + low rank: the favourable regime of the eigen-solver; the dense regime is second_workload)"
+                                    if args.hessian_init == "identity" else ""),
+                       "rccl_ranks": world if world > 1 else 0,
+                       "max_abs_dev_sharded_vs_whole_bohr": checks.get(args.hessian_init),
                        "eigen_solver": "reduction route (tridiagonalise + bisection + inverse iteration)" if max(sweeps) == 0
                                        else "one-sided Jacobi",
                        "jacobi_sweeps_last_step": [int(min(sweeps)), int(max(sweeps))]},

@@ -214,3 +214,49 @@ def test_teardown_order_of_sharded_band(order):
         for o in second:
             o.close()
         del junk
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_sharded_band_rccl_two_devices():
+    """Two ranks on two GPUs of one process (ncclCommInitAll): the first execution of ncclSend / ncclRecv / ncclAllGather of comm.hip with
+    more than one rank.  Skipped on one-GPU boxes (the driver's 8-GPU node runs it)."""
+    if _ngpu() < 2:
+        pytest.skip("needs two GPUs")
+    from multioptpy_amd.band import Band
+    from multioptpy_amd.parallel import ShardedBand
+    I, N = 8, 14
+    X = cases.band(I, N)
+    whole = Band(I, N)
+    sh = ShardedBand(I, N, [0, 1], transport="rccl")
+    assert sh.transport == "rccl"
+    for it in range(5):
+        E = np.zeros(I); G = np.zeros((I, N, 3))
+        for i in range(I):
+            E[i], G[i] = cases.lj(X[i])
+        whole.upload(X, E, G); whole.step(it)
+        ref = whole.download()
+        sh.upload(X, E, G); sh.step(it)
+        got = sh.download()
+        assert np.abs(got - ref).max() < 1e-12, (it, np.abs(got - ref).max())
+        X = ref / cases.BOHR2ANG
+    sh.close()
+    whole.close()
+
+
+def test_bench_two_processes_rccl():
+    """bench.py under torch.distributed.run with two ranks on two GPUs (the multi-process unique-id path): the run itself asserts that
+    the sharded result of the last timed step equals the whole-band trajectory.  Skipped on one-GPU boxes."""
+    if _ngpu() < 2:
+        pytest.skip("needs two GPUs")
+    import json
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29541", "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "2", "--images", "8", "--atoms", "40",
+                        "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["rccl_ranks"] == 2
+    assert line["config"]["max_abs_dev_sharded_vs_whole_bohr"] < 1e-10
