@@ -176,6 +176,7 @@ extern "C" int mopt_band_attach_comm(mopt_band *b, mopt_comm *c) {
     if (rc != MOPT_OK) return rc;
     b->comm = c;
     c->grp->bands[c->rank] = b;
+    if (R > 1) ctx->join_by_events = true;                   // (see common.hpp: no kernel of this context spins for a kernel of another stream any more)
     return MOPT_OK;
 }
 

@@ -185,6 +185,10 @@ struct mopt_ctx {
     std::map<std::string, mopt_timer> timers;
     int lds_limit = 65536;
     int num_cu = 256;
+    bool join_by_events = false;             // eigen-solver: join the divide-and-conquer chain with a stream-level event wait instead of the spinning k_dc_wait
+                                             // (set for image-sharded bands with more than one rank: their exchange stream is a fifth busy stream of the
+                                             // process, more than the default number of hardware queues, and a kernel that spins for a kernel queued behind
+                                             // it on a shared queue would stall until its time-out)
     long long n_retries = 0;                 // images solved again after a hand-off time-out (mopt_ctx_timing_read family "tri_retries")
     bool tri_no_persist = false;             // eigen-solver: take the launch-per-step tridiagonalisation (retry after a hand-off time-out)
     // early start of the leading block (k_early.hip): staging + flags (grow-only), and the D array known to hold the sentinel

@@ -16,6 +16,7 @@ constexpr int AQ_CH = 9;
 __global__ void __launch_bounds__(1024) k_apply_qt(int n, int NB, const double *__restrict__ A_, const double *__restrict__ T_,
                                                    const double *__restrict__ in_, double *__restrict__ out_) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ int s_nz[2];                                  // the staged block has a non-zero T factor (a block of trivial reflectors is the identity)
     const int ldv = n | 1;
     double *y = sm, *Vs = y + n, *Ts = Vs + (size_t)2 * 16 * ldv, *w = Ts + 2 * 256, *tt = w + 16;      // y[n], V[2][16][ldv], T[2][256], w[16], t[16]
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, c = tid >> 6;
@@ -37,14 +38,24 @@ __global__ void __launch_bounds__(1024) k_apply_qt(int n, int NB, const double *
     auto stage = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < AQ_CH; ++q) { const int i = lane + 64 * q; if (q < chn && i < n) Vs[((size_t)buf * 16 + c) * ldv + i] = r[q]; }
-        if (tid < 256) Ts[buf * 256 + tid] = tv;
+        if (tid < 256) { Ts[buf * 256 + tid] = tv; if (tv != 0.0) s_nz[buf] = 1; }
     };
+    if (tid == 0) { s_nz[0] = 0; s_nz[1] = 0; }
+    __syncthreads();
     fetch(0);
     stage(0);
     __syncthreads();
     int buf = 0;
     for (int beta = 0; beta < NB; ++beta) {
         fetch(beta + 1);                                     // in flight during the three phases below
+        if (tid == 0) s_nz[buf ^ 1] = 0;                     // (set again by the stage below, behind a barrier)
+        if (!s_nz[buf]) {                                    // (uniform) T = 0: B_beta = I
+            lds_barrier();
+            stage(buf ^ 1);
+            lds_barrier();
+            buf ^= 1;
+            continue;
+        }
         const double *V = Vs + (size_t)buf * 16 * ldv, *T = Ts + buf * 256;
         {   // w_c = v_c . y
             const double *vc = V + (size_t)c * ldv;

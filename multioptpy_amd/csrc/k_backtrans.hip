@@ -150,6 +150,11 @@ __global__ void __launch_bounds__(256) k_tri_larft(int n, int NB, const double *
     double *Gm = sm + (size_t)16 * ldv, *Tm = Gm + 16 * 17, *st = Tm + 16 * 17;     // Gram matrix, T, tau
     const int b = blockIdx.y, beta = blockIdx.x, tid = threadIdx.x, k0 = 16 * beta;
     const double *A = A_ + (size_t)b * n * n, *TAU = TAU_ + (size_t)b * n;
+    {
+        // a block of sixteen trivial reflectors (tau = 0) has T = 0: nothing to load or to form
+        const double tv = (tid < 16 && k0 + tid <= n - 3) ? TAU[k0 + tid] : 0.0;
+        if (!__syncthreads_or(tv != 0.0)) { T_[((size_t)b * NB + beta) * 256 + tid] = 0.0; return; }
+    }
     for (int e = tid; e < 16 * n; e += 256) {
         const int c = e / n, i = e - c * n, k = k0 + c;
         double v = 0.0;
@@ -180,8 +185,9 @@ __global__ void __launch_bounds__(256) k_tri_larft(int n, int NB, const double *
 
 template <int NT, int WPW>
 __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, const double *__restrict__ A_, const double *__restrict__ T_,
-                                                            const double *Zt_, const int *__restrict__ bend_, double *Vout_) {
+                                                            const double *Zt_, const int *__restrict__ bend_, double *Vout_, const double *__restrict__ TAU_) {
     // (Vout_ may be Zt_ itself: a wave reads its 16 vectors completely before it writes them)
+    __shared__ int s_kact;
     constexpr int LEN = 16 * NT;                                           // padded vector length
     constexpr int LDV = LEN + ((2 - LEN % 32 + 32) % 32);                   // = 2 mod 32: the 16 x 2 operand reads of step 1 hit 32 different bank pairs
     constexpr int NTHR = 64 * WPW, NTL = 256 / NTHR;      // T entries per thread
@@ -206,6 +212,18 @@ __global__ void __launch_bounds__(64 * WPW) k_tri_backtrans_mfma(int n, int NB, 
         for (int q = 0; q < 16 * WPW; ++q) { const int jj = blockIdx.x * (16 * WPW) + q; if (jj < n) { const int t = bend_[(size_t)b * n + jj]; tmax = t > tmax ? t : tmax; } }
         const int kf = tmax - 2 < 0 ? 0 : tmax - 2;
         beta_first = (kf / 16 < NB - 1) ? kf / 16 : NB - 1;
+    }
+    // blocks behind the last non-trivial reflector are the identity (tau = 0: a tridiagonalisation that stopped early on a diagonal
+    // trailing block, k_tri_persist3, or rows that needed no reflector): skipped as well
+    if (TAU_) {
+        if (tid == 0) s_kact = -1;
+        __syncthreads();
+        int last = -1;
+        for (int i = tid; i <= n - 3; i += NTHR) if (TAU_[(size_t)b * n + i] != 0.0) last = i;
+        if (last >= 0) atomicMax(&s_kact, last);
+        __syncthreads();
+        const int bl = s_kact < 0 ? -1 : s_kact / 16;
+        beta_first = bl < beta_first ? bl : beta_first;
     }
     // Staging map (WPW = 4: 256 threads): thread t carries row c = t / 16 of the block and the columns t % 16 + 16 m, one per
     // 16-column tile m -- 128-byte row segments, addresses that differ by constants, and tiles below the block's first
@@ -343,7 +361,7 @@ int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, co
         // thread, 320 / 608 workgroups): 0.58 / 1.11 ms against 0.148 ms
 #define BTW(NT_, W_) do { constexpr int LEN_ = 16 * NT_, LDV_ = LEN_ + ((2 - LEN_ % 32 + 32) % 32); const size_t lds = ((size_t)16 * LDV_ + 16 * 17) * 8; \
         MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_tri_backtrans_mfma<NT_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024)); \
-        hipLaunchKernelGGL((k_tri_backtrans_mfma<NT_, W_>), dim3((n + 16 * W_ - 1) / (16 * W_), batch), dim3(64 * W_), lds, ctx->stream, n, NB, d_A, d_T, (const double *)d_Vt, d_bend, d_Vout); } while (0)
+        hipLaunchKernelGGL((k_tri_backtrans_mfma<NT_, W_>), dim3((n + 16 * W_ - 1) / (16 * W_), batch), dim3(64 * W_), lds, ctx->stream, n, NB, d_A, d_T, (const double *)d_Vt, d_bend, d_Vout, d_TAU); } while (0)
 #define BTM(NT_) BTW(NT_, 4)
         if (nt16 <= 4) BTM(4); else if (nt16 <= 8) BTM(8); else if (nt16 <= 12) BTM(12); else if (nt16 <= 16) BTM(16); else if (nt16 <= 19) BTM(19);
         else if (nt16 <= 24) BTM(24); else if (nt16 <= 32) BTM(32); else BTM(38);

@@ -26,6 +26,13 @@
 #include "dc_logic.h"
 #include "ql_block.hpp"
 
+#ifndef MOPT_P3_DEFL_TOL
+#define MOPT_P3_DEFL_TOL 64.0  /* deflation tolerance per matrix entry in units of eps * max(|d|, |e| so far) */
+#endif
+#ifndef MOPT_P3_DEFLATE
+#define MOPT_P3_DEFLATE 1      /* early stop of the persistent tridiagonalisation on a diagonal trailing block, see k_tri_persist3 */
+#endif
+
 namespace mopt {
 
 constexpr double DEPS = 2.220446049250313e-16;
@@ -306,6 +313,15 @@ __device__ __forceinline__ void put16c(__amdgpu_buffer_rsrc_t rs, int byte_off, 
     const u64 bits = (u64)__double_as_longlong(v);
     u32x4 w;
     w[0] = (unsigned)bits; w[1] = tag; w[2] = (unsigned)(bits >> 32); w[3] = tag;
+    if (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 1);
+    else __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 16);
+}
+// the same with a flag in the top byte of the SECOND tag word (k_tri_persist3's deflation test: "this row is diagonal", see there)
+template <bool LOCAL>
+__device__ __forceinline__ void put16f(__amdgpu_buffer_rsrc_t rs, int byte_off, double v, unsigned tag, unsigned flag) {
+    const u64 bits = (u64)__double_as_longlong(v);
+    u32x4 w;
+    w[0] = (unsigned)bits; w[1] = tag; w[2] = (unsigned)(bits >> 32); w[3] = tag | (flag << 24);
     if (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 1);
     else __builtin_amdgcn_raw_buffer_store_b128(w, rs, byte_off, 0, 16);
 }
@@ -970,8 +986,9 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     // may then hold up to 50 doubles -- n = 600 on 16 workgroups per matrix, where 16 waves would spill)
     constexpr int RW0 = MOPT_P3_RW0, NW = NWV - RW0, NS = 64 * CH;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ int s_fail, s_xloc;
+    __shared__ int s_fail, s_xloc, s_defl, s_jump[2];
     __shared__ double s_mail[8];                             // [2][4] D, E, TAU of a step on their way to the storing wave
+    __shared__ double s_chk[2];                              // [2] deflation test of a step: tolerance (>= 0) or -1 = no test, see "Deflation" below
     long long t_poll = 0, t_pro = 0, t_main = 0, t_bar = 0, t0 = 0, t1 = 0;
     const long long c_start = prof ? clock64() : 0, w_start = prof ? wall_clock64() : 0;
     double *vb = sm, *wb = sm + 3 * NS;                     // v[3][NS], w[2][NS]
@@ -985,7 +1002,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
     u64 *PX = XCH_ + (size_t)b * xch_stride;                // [2][n][2]
     u64 *ROWX = PX + (size_t)4 * n;                         // [2][n][2]
-    if (tid == 0) s_fail = 0;
+    if (tid == 0) { s_fail = 0; s_defl = 0; s_chk[0] = -1.0; s_chk[1] = -1.0; s_jump[0] = -1; s_jump[1] = -1; }
     for (int i = tid; i < 5 * NS; i += blockDim.x) sm[i] = 0.0;
     int r_end = 0;
     for (int r = 0; r < rows_cap; ++r) r_end += ((g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC) < n) ? 1 : 0;
@@ -1057,12 +1074,32 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         if (g0i < n && g0i > last_row0) last_row0 = g0i;
     }
     double tau = 0.0;                                        // (wave 0) tau of the reflector in sv
+    // Deflation (round 3).  Hessians of quasi-Newton runs are identity (or a model matrix) + low rank: after m + 1 Householder steps the
+    // Krylov space of the first unit vector is exhausted, the pivot row's tail is rounding noise and the trailing block is diagonal to
+    // working precision -- the remaining n - m steps would build reflectors from noise.  Test, at no cost for dense matrices:
+    //   * a pivot-row tail with |x|^2 <= (n - lo) tol^2, tol = 8 eps max(|d|, |e| so far), counts as zero (no reflector, tau = 0);
+    //   * in the main pass of such a step every row wave also takes the largest |a_ij| over its live off-diagonal entries and sends
+    //     "<= tol" as a flag in the top byte of its p value's second tag word;
+    //   * wave 0 of every member sees all flags in the next prologue: if every live row is diagonal (and no reflector is pending: tau = 0),
+    //     all members stop at this step -- every row owner stores D = a_ii, E = 0, TAU = 0 for its rows.
+    // Dropping entries <= 8 eps ||T|| perturbs eigenvalues by a few 1e-15 ||T||, the size of the split criterion of k_tri_bisect.
+    double dmax = 0.0;                                       // (wave 0) largest |d|, |e| so far
+    bool chk_prev = false;                                   // (wave 0) the previous step asked for the flags
+    int defl_at = -1;                                        // first row of the diagonal trailing block when the reduction stopped early
+    int nsteps = 0;
+    // Jump.  The flags also say WHICH rows are not diagonal yet.  A row with the flag set has no live off-diagonal entry above the tolerance,
+    // in particular none in the columns of the other rows: the trailing block is diag (+) a block on the few rows without the flag (weak
+    // directions of the low-rank part that the Krylov space has not resolved to 1e-16 yet).  Rows lo .. r - 1 in front of the first such row
+    // r are final as they stand (D = a_ii, E = 0, no reflector), so the pivot moves to r in ONE step instead of r - lo trivial ones: the
+    // row owners store D, E, TAU of the rows passed over, the owner of the new pivot row publishes it, every live row publishes a (zero)
+    // p value -- the flow control of the exchange stays as it is -- and the loop goes on at step r - 1 (or r - 2: the exchange buffers
+    // alternate with the parity of the step, so a jump covers an odd number of steps).
     int vi0 = 0;                                             // v buffer of step k: (k + 1) % 3, kept incrementally
     int k = -1;
     // One Householder step, specialised at compile time on the first column chunk Q0 that still takes part: chunks below it
     // hold dead columns only (and have done so for three steps, so all three v buffers and both w buffers already carry
     // zeros there) and are not loaded, computed or stored.  Returns false when a hand-off timed out.
-    auto step = [&](auto q0c) -> bool {
+    auto step = [&](auto q0c) -> int {                       // 0: hand-off time-out, 1: done, 2: deflated (stop), 3: jump
         constexpr int Q0 = decltype(q0c)::value;
         const int lo = k + 1, cur = k & 1, nxt = cur ^ 1;
         const unsigned tag = (unsigned)(k + 2);
@@ -1090,7 +1127,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 for (int q = Q0; q < CH; ++q) {
                     const int jj = lane + 64 * q;
                     const bool need = (jj >= lo) & (jj < n);
-                    const bool got = (xr[q][1] == tag) & (xr[q][3] == tag) & ((k < 0) | ((xp[q][1] == tag) & (xp[q][3] == tag)));
+                    const bool got = (xr[q][1] == tag) & (xr[q][3] == tag) & ((k < 0) | ((xp[q][1] == tag) & ((xp[q][3] & 0x00FFFFFFu) == tag)));
                     ok = ok & (got | !need);
                 }
 #ifdef MOPT_P3_ABL_NOWAIT
@@ -1101,11 +1138,55 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 __builtin_amdgcn_s_sleep(1);
             }
             if (prof) { t1 = wall_clock64(); if (k >= 0) t_poll += t1 - t0; t0 = t1; }      // (k = -1: start-up skew, not a hand-off)
+            // ---- deflation: the flags of the previous main pass (only when that step asked for them; no reflector is pending then)
+            bool all_diag = false;
+            int kj = -1;                                     // >= 0: jump to step kj
+            if (chk_prev && k >= 0 && !s_fail) {
+                int cand = n;                                // first live row without the flag
+#pragma unroll
+                for (int q = Q0; q < CH; ++q) {
+                    const int jj = lane + 64 * q;
+                    const bool need = (jj >= lo) & (jj < n);
+                    if (need && (xp[q][3] >> 24) != 1u) cand = jj < cand ? jj : cand;
+                }
+                const int rmin = wave_min_int(cand);
+                all_diag = (rmin >= n);
+                if constexpr (TR > 0) {
+                    if (!all_diag) {
+                        int kk = rmin - 1;
+                        if (kk > k_last) kk = k_last;
+                        if (((kk - k) & 1) == 0) --kk;
+                        if (kk >= k + 3) kj = kk;
+                    }
+                }
+            }
+            if (all_diag || kj >= 0) {
+                // the pivot row lo itself: its owner may have left the kernel already (the pivot has reached its last row), so its diagonal
+                // entry is stored from the published row -- by every member, the same value (tau = 0: no update of step k is pending)
+                double dg_l = 0.0;
+#pragma unroll
+                for (int q = Q0; q < CH; ++q) {
+                    const int jj = lane + 64 * q;
+                    const double rj = __longlong_as_double((long long)((u64)xr[q][0] | ((u64)xr[q][2] << 32)));
+                    dg_l = (jj == lo) ? rj : dg_l;
+                }
+                const double dg = lane_bcast(dg_l, lo & 63);
+                if (lane == 0) { D[lo] = dg; E[lo] = 0.0; TAU[lo] = 0.0; if (all_diag) s_defl = 1; }
+                if (kj >= 0) {
+                    // the state step kj expects from a trivial step kj - 1: v = e_{kj+1} with tau = 0 (w comes out as zero), no flags asked for
+#pragma unroll
+                    for (int q = Q0; q < CH; ++q) svn[lane + 64 * q] = 0.0;
+                    if (lane == 0) { svn[kj + 1] = 1.0; s_chk[nxt & 1] = -1.0; }
+                    tau = 0.0;
+                    chk_prev = false;
+                }
+            }
+            if (lane == 0) s_jump[nxt & 1] = kj;
             // ---- w_k = p + c v (p = tau A v, c = -tau/2 p.v), then the reflector of step k+1 from the updated row lo
 #ifdef MOPT_P3_ABL_NOPRO
             if (k < 0)
 #endif
-            {
+            if (!all_diag && kj < 0) {
             const double v_lo = sv[lo];
             double vq[CH], wq[CH], rq[CH];
             double pvl = 0.0, plo_l = 0.0;
@@ -1138,7 +1219,11 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             const double xn2 = wave_sum(xl);
             const double alpha = lane_bcast(al_l, (lo + 1) & 63);
             const double diag = lane_bcast(dg_l, lo & 63);
-            const bool refl = (lo <= n - 3 && xn2 != 0.0);
+            dmax = fmax(dmax, fmax(fabs(diag), (lo + 1 < n) ? fabs(alpha) : 0.0));
+            const double tolv = MOPT_P3_DEFL_TOL * DEPS * dmax;
+            const int ntail = n - lo - 2;
+            const bool tiny = MOPT_P3_DEFLATE && (xn2 <= tolv * tolv * (double)(ntail > 1 ? ntail : 1));
+            const bool refl = (lo <= n - 3 && xn2 != 0.0 && !tiny);
             const double bt = -copysign(sqrt(alpha * alpha + xn2), alpha);
             const double betan = refl ? bt : alpha;
             const double taun = refl ? (bt - alpha) / bt : 0.0;
@@ -1149,7 +1234,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 const double vn = rq[q] * scal;
                 svn[jj] = vn;
             }
+            dmax = fmax(dmax, fabs(betan));
+            chk_prev = MOPT_P3_DEFLATE && (lo <= n - 3) && !refl;      // no reflector from this pivot row: is the trailing block diagonal already?
             if (lane == 0) {
+                s_chk[nxt & 1] = chk_prev ? tolv : -1.0;
                 svn[lo + 1] = 1.0;                           // (behind the vector stores: LDS operations of a wave stay in order)
                 // D, E, TAU of this step: left in LDS for the last wave, which stores them (and the reflector) behind its rows --
                 // workgroup 0 is on the critical path of every step and its wave 0 should carry nothing the others do not
@@ -1161,7 +1249,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
         } else if (prof) t0 = wall_clock64();
         lds_barrier();                                      // sw, svn (and the failure flag of the poll) complete
-        if (s_fail) return false;
+        if (s_fail) return 0;
+        if (s_defl) return 2;                                // (rare paths live outside this lambda: it is instantiated once per first live chunk)
+        if constexpr (TR > 0) { if (s_jump[nxt & 1] >= 0) return 3; }
+        const double chkv = s_chk[nxt & 1];                  // (wave-uniform) >= 0: this main pass also tests the rows for diagonality
         if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
         // ---- main pass: rank-2 update of the live rows with (v, w), then p_i = row_i . v' reduced inside the wave
         if constexpr (TR > 0 && NWV == 8) {
@@ -1205,8 +1296,15 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                             for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16c<false>(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u); }
                         }
                     }
+                    unsigned flag = 0u;
+                    if (chkv >= 0.0) {
+                        double mx = 0.0;
+#pragma unroll
+                        for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(areg[t][q]) : 0.0); }
+                        flag = (wave_max(mx) <= chkv) ? 1u : 0u;
+                    }
                     const double d0 = wave_sum63(d0v[t]);
-                    if (lane == 63) { if (xlocs) put16c<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u); else put16c<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u); }
+                    if (lane == 63) { if (xlocs) put16f<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); else put16f<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); }
                 }
             }
         } else if (!(RW0 && wid == 0)) {
@@ -1239,10 +1337,17 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                                 for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16c<false>(rsR, (nxt * n + jj) * 16, areg[t][q], tag + 1u); }
                             }
                         }
+                        unsigned flag = 0u;
+                        if (chkv >= 0.0) {                                              // (rare, wave-uniform) largest live off-diagonal entry of the row
+                            double mx = 0.0;
+#pragma unroll
+                            for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(areg[t][q]) : 0.0); }
+                            flag = (wave_max(mx) <= chkv) ? 1u : 0u;
+                        }
 #ifndef MOPT_P3_ABL_NORED
                         d0 = wave_sum63(d0);                                            // total in lane 63
 #endif
-                        if (lane == 63) { if (xlocs) put16c<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u); else put16c<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u); }
+                        if (lane == 63) { if (xlocs) put16f<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); else put16f<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); }
                     }
                 }
             } else {
@@ -1272,8 +1377,15 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
 #pragma unroll
                         for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn && jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, a[q], tag + 1u, xlocs); }
                     }
+                    unsigned flag = 0u;
+                    if (chkv >= 0.0) {
+                        double mx = 0.0;
+#pragma unroll
+                        for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(a[q]) : 0.0); }
+                        flag = (wave_max(mx) <= chkv) ? 1u : 0u;
+                    }
                     d0 = wave_sum63(d0);
-                    if (lane == 63) put16(rsP, (nxt * n + gi) * 16, d0, tag + 1u, xlocs);
+                    if (lane == 63) { if (xlocs) put16f<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); else put16f<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); }
                 }
             }
         }
@@ -1300,14 +1412,15 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             }
         }
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
-        return true;
+        return 1;
     };
     for (; k <= k_last; ++k) {
         if (my_last_row <= k + 1) break;                     // (uniform over the workgroup)
         const int lo3 = k + 1 - 3;                           // a chunk is skipped once it has been dead for three steps
         int qd = lo3 < 0 ? 0 : lo3 >> 6;
         if (qd > CH - 1) qd = CH - 1;
-        bool ok = true;
+        int ok = 1;
+        ++nsteps;
         switch (qd < 7 ? qd : 7) {
             case 0: ok = step(std::integral_constant<int, 0>{}); break;
             case 1: if constexpr (CH > 1) ok = step(std::integral_constant<int, 1>{}); break;
@@ -1318,11 +1431,60 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             case 6: if constexpr (CH > 6) ok = step(std::integral_constant<int, 6>{}); break;
             default: if constexpr (CH > 7) ok = step(std::integral_constant<int, 7>{}); break;
         }
-        if (!ok) break;
+        if (ok == 0) break;
+        if (ok == 2) {
+            // rows lo .. n-1 are final and diagonal: every owner stores its rows' D, E = 0, TAU = 0 (row lo, the pivot row of this step, was stored
+            // by wave 0 in its prologue); the rows of A behind lo keep the input matrix -- finite numbers behind tau = 0, never used
+            const int lo = k + 1;
+            defl_at = lo;
+            if constexpr (TR > 0) {
+#pragma unroll
+                for (int t = 0; t < TR; ++t) {
+                    const int gi = gi_t[t];
+                    if (gi > lo) {
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) if ((gi >> 6) == q && lane == (gi & 63)) D[gi] = areg[t][q];
+                        if (lane == 0) { E[gi] = 0.0; TAU[gi] = 0.0; }
+                    }
+                }
+            } else {
+                for (int r = (wid >= RW0) ? wid - RW0 : r_end; r < r_end; r += NW) {
+                    const int gi = (g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC);
+                    if (gi > lo && lane == 0) { D[gi] = Aloc[r * ns + gi]; E[gi] = 0.0; TAU[gi] = 0.0; }
+                }
+            }
+            if (tid == 0) __hip_atomic_store(&ROWX[(size_t)4 * n + G], (u64)(lo + 1) | ((u64)nsteps << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for k_tri_tail (every member writes the same word; high half: steps taken, for the developer print)
+            break;
+        }
+        if constexpr (TR > 0) {
+            if (ok == 3) {
+                // jump: rows lo + 1 .. lo2 - 1 are final (row lo was stored by wave 0), row lo2 is the next pivot row
+                const int lo = k + 1, kjv = s_jump[(k & 1) ^ 1];
+                const int lo2 = kjv + 1, nx2 = kjv & 1;      // (nx2 == the step's "next" buffer: a jump covers an odd number of steps)
+                const unsigned tag2 = (unsigned)(kjv + 2);
+#pragma unroll
+                for (int t = 0; t < TR; ++t) {
+                    const int gi = gi_t[t];
+                    if (gi > lo && gi < lo2) {
+#pragma unroll
+                        for (int q = 0; q < CH; ++q) if ((gi >> 6) == q && lane == (gi & 63)) D[gi] = areg[t][q];
+                        if (lane == 0) { E[gi] = 0.0; TAU[gi] = 0.0; }
+                    } else if (gi >= lo2) {
+                        if (gi == lo2) {
+#pragma unroll
+                            for (int q = 0; q < CH; ++q) { const int jj = lane + 64 * q; if (jj < n) put16(rsR, (nx2 * n + jj) * 16, areg[t][q], tag2, xlocs); }
+                        }
+                        if (lane == 63) { if (xlocs) put16f<true>(rsP, (nx2 * n + gi) * 16, 0.0, tag2, 0u); else put16f<false>(rsP, (nx2 * n + gi) * 16, 0.0, tag2, 0u); }
+                    }
+                }
+                k = kjv - 1;                                 // (the loop increment makes it kjv)
+            }
+        }
     }
     if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = 0; q[3] = t_main; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
     __syncthreads();
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], TRI_FAIL_TIMEOUT);      // (every s_fail of this kernel is a hand-off that timed out)
+    if (defl_at >= 0) return;                                // (stopped early: D, E, TAU of the remaining rows are stored, k_tri_tail finds the deflation word)
     if (k_last < n - 3) {
         // hand-over to k_tri_tail: the live rows (behind pivot row K) go back to A, all n columns of each (columns <= K are dead)
         const int K = k_last + 1;
@@ -2158,7 +2320,7 @@ int mopt_launch_backtrans(mopt_ctx *ctx, int n, int batch, const double *d_A, co
                           double *d_Vout = nullptr);
 int mopt_tri_tail_max();
 int mopt_launch_tri_tail(mopt_ctx *ctx, hipStream_t st, int n, int K, int batch, double *d_A, double *d_D, double *d_E, double *d_TAU,
-                         long long *d_prof = nullptr);
+                         long long *d_prof = nullptr, const unsigned long long *d_defl = nullptr, size_t defl_stride = 0);
 size_t mopt_dc_scratch_bytes(int n, int batch);
 int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_D, const double *d_E, int *d_flag, double *d_WT,
                    double *d_Vt, double *d_Z2, int *d_bstart, int *d_bend, int *d_fail, void *scratch);
@@ -2326,7 +2488,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         long long *d_prof = nullptr;
         if (tri_env("MOPT_TRI_PROF")) { hipMalloc(&d_prof, (size_t)batch * G * 64); hipMemset(d_prof, 0, (size_t)batch * G * 64); }
         const int per = ctx->num_cu / G;                     // matrices per launch: every workgroup must be resident
-        const size_t xwords = (size_t)8 * n + G;               // p vectors, pivot rows (two buffers each, two tagged words per value), XCC ids
+        const size_t xwords = (size_t)8 * n + G + 1;           // p vectors, pivot rows (two buffers each, two tagged words per value), XCC ids, deflation word
         if (!(pre_cleared && xwords <= (size_t)8 * n + 64)) MOPT_HIP_TRY(ctx, hipMemset2DAsync(d_Vt, (size_t)n * n * 8, 0, xwords * 8, (size_t)batch, ctx->stream));
         int try_local = tri_env("MOPT_TRI_NOLOCAL") ? 0 : 1;
         // early start of the leading block's eigen-solve on the helper stream, next to the (first) persistent launch (k_early.hip);
@@ -2377,8 +2539,18 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP, &nmat, &per_x, &try_local, &k_last};
             MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(8 * per_x * G), dim3(nthreads), args, lds_use, ctx->stream));
         }
+        if (tri_env("MOPT_TRI_DEFLDBG")) {                    // developer aid: where each matrix' reduction stopped (0 = ran to the end)
+            std::vector<unsigned long long> w(batch);
+            hipStreamSynchronize(ctx->stream);
+            hipMemcpy2D(w.data(), 8, (const unsigned long long *)d_Vt + (size_t)8 * n + G, (size_t)n * n * 8, 8, (size_t)batch, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[defl] n=%d:", n);
+            for (int b = 0; b < batch; ++b) fprintf(stderr, " %llu/%llu", w[b] & 0xffffffffull, w[b] >> 32);
+            fprintf(stderr, "\n");
+        }
         if (k_last < n - 3) {
-            const int rc = mopt_launch_tri_tail(ctx, ctx->stream, n, k_last + 1, batch, d_A, d_D, d_E, d_TAU);
+            // (a matrix whose reduction stopped early on a diagonal trailing block has left a non-zero deflation word behind its exchange area)
+            const int rc = mopt_launch_tri_tail(ctx, ctx->stream, n, k_last + 1, batch, d_A, d_D, d_E, d_TAU, nullptr,
+                                                (const unsigned long long *)d_Vt + (size_t)8 * n + G, (size_t)n * n);
             if (rc != MOPT_OK) return rc;
         }
         if (d_prof) {
@@ -2622,7 +2794,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         unsigned *word = (unsigned *)ctx->arena;                 // (head of the arena: zeroed when it is allocated)
         hipLaunchKernelGGL(k_dc_signal, dim3(1), dim3(64), 0, ctx->side3, word, epoch);
         MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join5, ctx->side3));      // (waited for at the start of the next solve: the chain reads this solve's buffers)
-        if (serialized_dispatch() || (tri_env("MOPT_TRI_DCJOIN") && atoi(tri_env("MOPT_TRI_DCJOIN")) == 1)) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
+        if (serialized_dispatch() || ctx->join_by_events || (tri_env("MOPT_TRI_DCJOIN") && atoi(tri_env("MOPT_TRI_DCJOIN")) == 1)) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
         else hipLaunchKernelGGL(k_dc_wait, dim3(1), dim3(64), 0, ctx->stream, batch, (const int *)d_dcflag, (const unsigned *)word, epoch, d_fail);
     }
     if (bt_mfma) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the T factors (side stream)

@@ -40,7 +40,10 @@ __device__ __forceinline__ double tail_rcp(double x) {
 // NW waves per workgroup (16: 128 registers per lane, 8: 256 registers per lane -- the 3 x 24 tile of m <= 192 with its operands)
 template <int CH, int NW>
 __global__ void __launch_bounds__(64 * NW) k_tri_tail(int n, int K, double *__restrict__ A_, double *__restrict__ D_, double *__restrict__ E_,
-                                                      double *__restrict__ TAU_, long long *__restrict__ prof) {
+                                                      double *__restrict__ TAU_, long long *__restrict__ prof, const unsigned long long *__restrict__ defl,
+                                                      size_t defl_stride) {
+    // (the persistent kernel in front stopped early for this matrix: its trailing block is diagonal and D, E, TAU are complete)
+    if (defl && defl[(size_t)blockIdx.x * defl_stride] != 0ull) return;
 #ifdef MOPT_TAIL_PROF
     // developer build (tools/ubench/tail_main.hip): shader-clock stamps of wave 0 around the phases of a step, summed over the steps
     long long tp[6] = {0, 0, 0, 0, 0, 0}, tc0 = 0, tc1 = 0;
@@ -274,7 +277,7 @@ __global__ void __launch_bounds__(64 * NW) k_tri_tail(int n, int K, double *__re
 // Tridiagonalises rows / columns K + 1 .. n - 1 of every matrix of the batch (K = -1: the whole matrix), n - K - 1 <= 192.
 int mopt_tri_tail_max() { return 192; }
 int mopt_launch_tri_tail(mopt_ctx *ctx, hipStream_t st, int n, int K, int batch, double *d_A, double *d_D, double *d_E, double *d_TAU,
-                         long long *d_prof) {
+                         long long *d_prof, const unsigned long long *d_defl, size_t defl_stride) {
     using namespace mopt;
     static const bool W8 = !(getenv("MOPT_TAIL_W8") && atoi(getenv("MOPT_TAIL_W8")) == 0);
     const int m = n - K - 1;
@@ -285,7 +288,7 @@ int mopt_launch_tri_tail(mopt_ctx *ctx, hipStream_t st, int n, int K, int batch,
     const int nthreads = (ch == 3 && W8) ? 512 : 1024;
     if (lds > 64 * 1024) MOPT_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     int n_ = n, K_ = K;
-    void *args[] = {&n_, &K_, &d_A, &d_D, &d_E, &d_TAU, &d_prof};
+    void *args[] = {&n_, &K_, &d_A, &d_D, &d_E, &d_TAU, &d_prof, &d_defl, &defl_stride};
     MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(batch), dim3(nthreads), args, lds, st));
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
