@@ -24,6 +24,7 @@ struct mopt_band {
     int warm_enabled = 1;
     int steps_since_check = 0;       // band steps enqueued since the host last looked at the failure words (download / mopt_band_failures)
     int last_optimize_num = 0; bool last_have_prev = false, last_have_coef = false;      // of the last step: what a repeat of its tail needs
+    bool dense_hessians = false;     // an explicit (exact / model) Hessian has been handed to an owned image: no low-rank structure to expect
     bool fused_step = false;         // this step takes the fused path (decided in phase a, where the TR/rot basis is forked)
     std::vector<char> H_sym;         // per owned image: the resident Hessian is known to be bitwise symmetric (identity, model Hessian,
                                      // a symmetric upload): the band then takes the fused update + projection path (k_fused.hip)

@@ -360,6 +360,7 @@ extern "C" int mopt_band_set_hessian(mopt_band *b, int image, const double *H) {
             MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
         b->H_sym[loc] = 1;
+        b->dense_hessians = true;
     } else {
         b->H_sym[loc] = 1;
         std::vector<double> eye(nn, 0.0);
@@ -588,6 +589,7 @@ int mopt_band_step_phase_b(mopt_band *b, int optimize_num) {
     wk.x = b->X + (size_t)first * n; wk.bg = b->G + (size_t)first * n; wk.g = wk.bg;
     wk.px = b->pX + (size_t)first * n; wk.pg = b->pG + (size_t)first * n;
     const bool warm = b->warm_enabled && b->have_vecs && b->warm_run < 64;
+    wk.defl_hint = b->dense_hessians ? 0 : 1;
     int rc = mopt_rsirfo_pipeline(ctx, wk, n, count, have_prev, false, nullptr, wk.H, warm, fused ? &fb : nullptr);
     b->warm_run = warm ? b->warm_run + 1 : 0;
     b->have_vecs = true;
@@ -630,6 +632,7 @@ extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par
     hipStreamSynchronize(ctx->stream);
     hipFree(d_par);
     b->have_vecs = false;
+    b->dense_hessians = true;
     b->H_sym.assign((size_t)b->count, 1);
     return rc;
 }

@@ -170,6 +170,9 @@ struct WaveRed {
 // ---- host side --------------------------------------------------------------------------
 struct mopt_timer { std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; double ms = 0.0; int64_t launches = 0; };
 
+// outcome of the last deflating tridiagonalisation on a workspace, read back without waiting (k_tridiag.hip)
+struct DeflProbe { const void *key = nullptr; int *pin = nullptr; int cap = 0; hipEvent_t ev = nullptr; bool pending = false; int batch = 0, dense_streak = 0, skip_left = 0; };
+
 struct mopt_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -185,6 +188,7 @@ struct mopt_ctx {
     std::map<std::string, mopt_timer> timers;
     int lds_limit = 65536;
     int num_cu = 256;
+    DeflProbe defl;
     bool join_by_events = false;             // eigen-solver: join the divide-and-conquer chain with a stream-level event wait instead of the spinning k_dc_wait
                                              // (set for image-sharded bands with more than one rank: their exchange stream is a fifth busy stream of the
                                              // process, more than the default number of hardware queues, and a kernel that spins for a kernel queued behind

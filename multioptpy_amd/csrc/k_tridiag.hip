@@ -972,11 +972,13 @@ __global__ void __launch_bounds__(1024) k_tri_persist2(int n, int G, int rows_ca
 // (v = w = 0) need no predicate -- they ride along with zero weights.  Column lo of the live rows and row lo itself pick up
 // finite garbage (w_lo, v_lo = 1 are not zero); neither is read again (v'_lo = 0, and only columns > lo of a row are published).
 // Exchange words per matrix: P [2][n][2], ROW [2][n][2], XID [G].
-template <int CH, int TR, int NWV = 16>
+// DEFL = false: the same kernel without the deflation test (no flags, no control word: the launcher takes it for workspaces whose last solves
+// did not deflate -- dense Hessians --, where the test is pure overhead: 7.56 against 6.50 ms for 64 matrices of n = 600)
+template <int CH, int TR, int NWV = 16, bool DEFL = true>
 __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int rows_cap, double *__restrict__ A_, double *__restrict__ D_,
                                                        double *__restrict__ E_, double *__restrict__ TAU_, u64 *__restrict__ XCH_,
                                                        size_t xch_stride, int *__restrict__ fail_, long long *__restrict__ prof, int nmat,
-                                                       int per_x, int try_local, int k_last) {
+                                                       int per_x, int try_local, int k_last, int *__restrict__ defl_out) {
     // k_last = n - 3: the whole reduction.  k_last < n - 3: stop behind pivot row K = k_last + 1 and leave the rows below it (current up
     // to the reflector of row K - 1) in A for k_tri_tail (k_tritail.hip), which finishes the block inside one compute unit.
     // MOPT_P3_RW0 = 1 makes wave 0 a pure communication wave (polls, prologue, no rows), back at the exchange right behind
@@ -986,7 +988,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     // may then hold up to 50 doubles -- n = 600 on 16 workgroups per matrix, where 16 waves would spill)
     constexpr int RW0 = MOPT_P3_RW0, NW = NWV - RW0, NS = 64 * CH;
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ int s_fail, s_xloc, s_defl, s_jump[2];
+    __shared__ int s_fail, s_xloc, s_defl, s_jump[2];       // s_defl: stop (trailing block diagonal); s_jump[2]: >= 0 jump to that step
     __shared__ double s_mail[8];                             // [2][4] D, E, TAU of a step on their way to the storing wave
     __shared__ double s_chk[2];                              // [2] deflation test of a step: tolerance (>= 0) or -1 = no test, see "Deflation" below
     long long t_poll = 0, t_pro = 0, t_main = 0, t_bar = 0, t0 = 0, t1 = 0;
@@ -1111,6 +1113,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             if (prof) t0 = wall_clock64();
             u32x4 xp[CH], xr[CH];
             unsigned spins = 0;
+            int cand = n;
 #if MOPT_P3_PREDELAY > 0
             __builtin_amdgcn_s_sleep(MOPT_P3_PREDELAY);      // see the note at the definition
 #endif
@@ -1123,12 +1126,14 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                     xp[q] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (cur * n + jc) * 16, 0, 16);
                 }
                 bool ok = true;
+                cand = n;
 #pragma unroll
                 for (int q = Q0; q < CH; ++q) {
                     const int jj = lane + 64 * q;
                     const bool need = (jj >= lo) & (jj < n);
                     const bool got = (xr[q][1] == tag) & (xr[q][3] == tag) & ((k < 0) | ((xp[q][1] == tag) & ((xp[q][3] & 0x00FFFFFFu) == tag)));
                     ok = ok & (got | !need);
+                    if constexpr (DEFL) cand = (need & ((xp[q][3] >> 24) != 1u) & (jj < cand)) ? jj : cand;      // first live row of this lane without the "diagonal" flag
                 }
 #ifdef MOPT_P3_ABL_NOWAIT
                 ok = true;                                   // (timing ablation: one load pass, no waiting; results are garbage)
@@ -1138,17 +1143,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 __builtin_amdgcn_s_sleep(1);
             }
             if (prof) { t1 = wall_clock64(); if (k >= 0) t_poll += t1 - t0; t0 = t1; }      // (k = -1: start-up skew, not a hand-off)
-            // ---- deflation: the flags of the previous main pass (only when that step asked for them; no reflector is pending then)
+            // ---- deflation: the flags of the previous main pass (only when that step asked for them; no reflector is pending then: tau = 0)
             bool all_diag = false;
             int kj = -1;                                     // >= 0: jump to step kj
-            if (chk_prev && k >= 0 && !s_fail) {
-                int cand = n;                                // first live row without the flag
-#pragma unroll
-                for (int q = Q0; q < CH; ++q) {
-                    const int jj = lane + 64 * q;
-                    const bool need = (jj >= lo) & (jj < n);
-                    if (need && (xp[q][3] >> 24) != 1u) cand = jj < cand ? jj : cand;
-                }
+            if (DEFL && chk_prev && k >= 0 && !s_fail) {
                 const int rmin = wave_min_int(cand);
                 all_diag = (rmin >= n);
                 if constexpr (TR > 0) {
@@ -1160,33 +1158,13 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                     }
                 }
             }
-            if (all_diag || kj >= 0) {
-                // the pivot row lo itself: its owner may have left the kernel already (the pivot has reached its last row), so its diagonal
-                // entry is stored from the published row -- by every member, the same value (tau = 0: no update of step k is pending)
-                double dg_l = 0.0;
-#pragma unroll
-                for (int q = Q0; q < CH; ++q) {
-                    const int jj = lane + 64 * q;
-                    const double rj = __longlong_as_double((long long)((u64)xr[q][0] | ((u64)xr[q][2] << 32)));
-                    dg_l = (jj == lo) ? rj : dg_l;
-                }
-                const double dg = lane_bcast(dg_l, lo & 63);
-                if (lane == 0) { D[lo] = dg; E[lo] = 0.0; TAU[lo] = 0.0; if (all_diag) s_defl = 1; }
-                if (kj >= 0) {
-                    // the state step kj expects from a trivial step kj - 1: v = e_{kj+1} with tau = 0 (w comes out as zero), no flags asked for
-#pragma unroll
-                    for (int q = Q0; q < CH; ++q) svn[lane + 64 * q] = 0.0;
-                    if (lane == 0) { svn[kj + 1] = 1.0; s_chk[nxt & 1] = -1.0; }
-                    tau = 0.0;
-                    chk_prev = false;
-                }
-            }
-            if (lane == 0) s_jump[nxt & 1] = kj;
+            // (the prologue below runs in either case: row lo carries the flag, so its tail is negligible, no reflector comes out of it and
+            // D, E of the row are the numbers it computes anyway)
             // ---- w_k = p + c v (p = tau A v, c = -tau/2 p.v), then the reflector of step k+1 from the updated row lo
 #ifdef MOPT_P3_ABL_NOPRO
             if (k < 0)
 #endif
-            if (!all_diag && kj < 0) {
+            {
             const double v_lo = sv[lo];
             double vq[CH], wq[CH], rq[CH];
             double pvl = 0.0, plo_l = 0.0;
@@ -1222,7 +1200,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             dmax = fmax(dmax, fmax(fabs(diag), (lo + 1 < n) ? fabs(alpha) : 0.0));
             const double tolv = MOPT_P3_DEFL_TOL * DEPS * dmax;
             const int ntail = n - lo - 2;
-            const bool tiny = MOPT_P3_DEFLATE && (xn2 <= tolv * tolv * (double)(ntail > 1 ? ntail : 1));
+            const bool tiny = DEFL && MOPT_P3_DEFLATE && (xn2 <= tolv * tolv * (double)(ntail > 1 ? ntail : 1));
             const bool refl = (lo <= n - 3 && xn2 != 0.0 && !tiny);
             const double bt = -copysign(sqrt(alpha * alpha + xn2), alpha);
             const double betan = refl ? bt : alpha;
@@ -1235,10 +1213,17 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 svn[jj] = vn;
             }
             dmax = fmax(dmax, fabs(betan));
-            chk_prev = MOPT_P3_DEFLATE && (lo <= n - 3) && !refl;      // no reflector from this pivot row: is the trailing block diagonal already?
+            const bool special = all_diag || kj >= 0;        // stop or jump: the step has no main pass
+            chk_prev = DEFL && MOPT_P3_DEFLATE && (lo <= n - 3) && !refl && !special;      // no reflector from this pivot row: is the trailing block diagonal already?
             if (lane == 0) {
-                s_chk[nxt & 1] = chk_prev ? tolv : -1.0;
-                svn[lo + 1] = 1.0;                           // (behind the vector stores: LDS operations of a wave stay in order)
+                if constexpr (DEFL) { s_chk[nxt & 1] = chk_prev ? tolv : -1.0; s_jump[nxt & 1] = kj; if (all_diag) s_defl = 1; }
+                if (special) {
+                    // the pivot row's owner may have left the kernel already (the pivot has reached its last row): its D, E, TAU are stored
+                    // here, by every member the same numbers (taun = 0)
+                    D[lo] = diag; E[lo] = (lo + 1 < n) ? betan : 0.0; TAU[lo] = taun;
+                }
+                // (jump: the state step kj expects from a trivial step kj - 1 is v = e_{kj+1} with tau = 0)
+                svn[(kj >= 0 ? kj : lo) + 1] = 1.0;          // (behind the vector stores: LDS operations of a wave stay in order)
                 // D, E, TAU of this step: left in LDS for the last wave, which stores them (and the reflector) behind its rows --
                 // workgroup 0 is on the critical path of every step and its wave 0 should carry nothing the others do not
                 // (member 0 while it stores the results; every member once that duty moves around, see below)
@@ -1250,9 +1235,12 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         } else if (prof) t0 = wall_clock64();
         lds_barrier();                                      // sw, svn (and the failure flag of the poll) complete
         if (s_fail) return 0;
-        if (s_defl) return 2;                                // (rare paths live outside this lambda: it is instantiated once per first live chunk)
-        if constexpr (TR > 0) { if (s_jump[nxt & 1] >= 0) return 3; }
-        const double chkv = s_chk[nxt & 1];                  // (wave-uniform) >= 0: this main pass also tests the rows for diagonality
+        double chkv = -1.0;                                  // (wave-uniform) >= 0: this main pass also tests the rows for diagonality
+        if constexpr (DEFL) {
+            if (s_defl) return 2;                            // (rare paths live outside this lambda: it is instantiated once per first live chunk)
+            if constexpr (TR > 0) { if (s_jump[nxt & 1] >= 0) return 3; }
+            chkv = s_chk[nxt & 1];
+        }
         if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
         // ---- main pass: rank-2 update of the live rows with (v, w), then p_i = row_i . v' reduced inside the wave
         if constexpr (TR > 0 && NWV == 8) {
@@ -1297,7 +1285,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                         }
                     }
                     unsigned flag = 0u;
-                    if (chkv >= 0.0) {
+                    if (DEFL && chkv >= 0.0) {
                         double mx = 0.0;
 #pragma unroll
                         for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(areg[t][q]) : 0.0); }
@@ -1338,7 +1326,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                             }
                         }
                         unsigned flag = 0u;
-                        if (chkv >= 0.0) {                                              // (rare, wave-uniform) largest live off-diagonal entry of the row
+                        if (DEFL && chkv >= 0.0) {                                      // (rare, wave-uniform) largest live off-diagonal entry of the row
                             double mx = 0.0;
 #pragma unroll
                             for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(areg[t][q]) : 0.0); }
@@ -1378,7 +1366,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                         for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn && jj > lo && jj < n) put16(rsR, (nxt * n + jj) * 16, a[q], tag + 1u, xlocs); }
                     }
                     unsigned flag = 0u;
-                    if (chkv >= 0.0) {
+                    if (DEFL && chkv >= 0.0) {
                         double mx = 0.0;
 #pragma unroll
                         for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(a[q]) : 0.0); }
@@ -1453,6 +1441,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                     if (gi > lo && lane == 0) { D[gi] = Aloc[r * ns + gi]; E[gi] = 0.0; TAU[gi] = 0.0; }
                 }
             }
+            if (tid == 0 && defl_out && ((n - 1) / TRI_RC) % G == g) defl_out[b] = lo + 1;      // (outcome for the launcher's choice of kernel, see DeflProbe)
             if (tid == 0) __hip_atomic_store(&ROWX[(size_t)4 * n + G], (u64)(lo + 1) | ((u64)nsteps << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for k_tri_tail (every member writes the same word; high half: steps taken, for the developer print)
             break;
         }
@@ -1485,6 +1474,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     __syncthreads();
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], TRI_FAIL_TIMEOUT);      // (every s_fail of this kernel is a hand-off that timed out)
     if (defl_at >= 0) return;                                // (stopped early: D, E, TAU of the remaining rows are stored, k_tri_tail finds the deflation word)
+    if (DEFL && tid == 0 && defl_out && ((n - 1) / TRI_RC) % G == g) defl_out[b] = 0;      // (ran to the end: the owner of the last row is the one member that always does)
     if (k_last < n - 3) {
         // hand-over to k_tri_tail: the live rows (behind pivot row K) go back to A, all n columns of each (columns <= K are dead)
         const int K = k_last + 1;
@@ -2329,7 +2319,7 @@ int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double
 // d_Z2: batch*(n*n + MOPT_TRI_T_DOUBLES(n)) doubles (scratch copy of the eigenvectors for the cluster orthogonalisation, then the T factors of the blocked back-transformation).  d_bstart, d_bend: batch*n ints; d_cstart: 2*batch*n ints (tight and loose cluster tables); d_ncl: 2*batch ints; d_fail: batch ints.
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook, int *d_sticky) {
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook, int *d_sticky, int *d_defl, int defl_hint) {
     using namespace mopt;
     if (n < 3) { ctx->err = "tridiagonal eigen-solver needs n >= 3"; return MOPT_E_ARG; }
     if (hook) hook->used = false;
@@ -2450,7 +2440,21 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         const void *fn = nullptr;
         const int cht = cht_for();                           // the CH the kernel is instantiated with
         size_t lds_use = ((size_t)rows * (((n + 63) / 64) * 64) + (size_t)5 * 64 * cht) * 8;
-#define P3(C, T) ((const void *)k_tri_persist3<C, T>)
+        // With or without the deflation test?  With it, unless the last solves on this workspace did not deflate a single matrix (dense
+        // Hessians): the outcome of a solve is copied to pinned memory on a helper stream and looked at -- without waiting -- by the next
+        // call; two all-dense solves in a row switch to the plain kernel for 24 solves, then the test runs again.
+        bool defl = !tri_env("MOPT_TRI_NODEFL") && defl_hint != 0;      // (hint 0: the caller knows its matrices are dense -- a band started from exact or model Hessians)
+        DeflProbe &pr = ctx->defl;
+        if (pr.key != (const void *)d_D) { pr.key = (const void *)d_D; pr.pending = false; pr.dense_streak = 0; pr.skip_left = 0; }
+        if (pr.pending && hipEventQuery(pr.ev) == hipSuccess) {
+            int cnt = 0;
+            for (int b = 0; b < pr.batch; ++b) cnt += pr.pin[b] != 0;
+            pr.pending = false;
+            if (cnt == 0) { if (++pr.dense_streak >= 2) { pr.skip_left = 24; pr.dense_streak = 0; } } else pr.dense_streak = 0;
+        }
+        if (!d_defl || tri_env("MOPT_TRI_DEFLALWAYS")) { pr.skip_left = 0; }
+        if (pr.skip_left > 0) { --pr.skip_left; defl = false; }
+#define P3(C, T) (defl ? (const void *)k_tri_persist3<C, T, 16, true> : (const void *)k_tri_persist3<C, T, 16, false>)
 #define P3T(C) (tr == 1 ? P3(C, 1) : tr == 2 ? P3(C, 2) : P3(C, 3))
         if (!tri_env("MOPT_TRI_NOREG") && ch >= 2 && ch <= 8 && tr >= 1 && tr <= 3 && ch * tr <= 16) {
             switch (ch <= 6 ? ch : 8) {
@@ -2465,7 +2469,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
         int nthreads = 1024;
         if (!fn && tr8 > 0) {
-#define P3W8(C, T) ((const void *)k_tri_persist3<C, T, 8>)
+#define P3W8(C, T) (defl ? (const void *)k_tri_persist3<C, T, 8, true> : (const void *)k_tri_persist3<C, T, 8, false>)
             const int c8 = ch <= 8 ? 8 : 10;
             fn = (c8 == 8) ? (tr8 == 4 ? P3W8(8, 4) : P3W8(8, 5)) : (tr8 == 4 ? P3W8(10, 4) : P3W8(10, 5));
 #undef P3W8
@@ -2536,8 +2540,24 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             size_t stride = (size_t)n * n;
             int *pF = d_fail + b0;
             long long *pP = d_prof ? d_prof + (size_t)b0 * G * 8 : nullptr;
-            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP, &nmat, &per_x, &try_local, &k_last};
+            int *pDf = d_defl ? d_defl + b0 : nullptr;
+            void *args[] = {&n_, &G_, &rows, &pA, &pD, &pE, &pT, &pX, &stride, &pF, &pP, &nmat, &per_x, &try_local, &k_last, &pDf};
             MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(8 * per_x * G), dim3(nthreads), args, lds_use, ctx->stream));
+        }
+        if (defl && d_defl && !pr.pending) {                  // the outcome of this solve, for the next call (helper stream, nobody waits for it)
+            if (pr.cap < batch) {
+                if (pr.pin) hipHostFree(pr.pin);
+                pr.pin = nullptr; pr.cap = 0;
+                if (hipHostMalloc((void **)&pr.pin, (size_t)batch * sizeof(int), hipHostMallocDefault) == hipSuccess) pr.cap = batch;
+            }
+            if (!pr.ev) hipEventCreateWithFlags(&pr.ev, hipEventDisableTiming);
+            if (pr.cap >= batch && pr.ev) {
+                MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_fork5, ctx->stream));
+                MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->side3, ctx->ev_fork5, 0));
+                MOPT_HIP_TRY(ctx, hipMemcpyAsync(pr.pin, d_defl, (size_t)batch * sizeof(int), hipMemcpyDeviceToHost, ctx->side3));
+                MOPT_HIP_TRY(ctx, hipEventRecord(pr.ev, ctx->side3));
+                pr.pending = true; pr.batch = batch;
+            }
         }
         if (tri_env("MOPT_TRI_DEFLDBG")) {                    // developer aid: where each matrix' reduction stopped (0 = ran to the end)
             std::vector<unsigned long long> w(batch);

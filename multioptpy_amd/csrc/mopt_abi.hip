@@ -111,6 +111,8 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipEventDestroy(ctx->ev_fork5); hipEventDestroy(ctx->ev_join5);
     hipEventDestroy(ctx->ev_fork6); hipEventDestroy(ctx->ev_join6);
     if (ctx->early_buf) hipFree(ctx->early_buf);
+    if (ctx->defl.ev) { hipEventSynchronize(ctx->defl.ev); hipEventDestroy(ctx->defl.ev); }
+    if (ctx->defl.pin) hipHostFree(ctx->defl.pin);
     pin_release(ctx);
     hipStreamDestroy(ctx->side3);
     hipStreamDestroy(ctx->side2);

@@ -13,7 +13,7 @@ constexpr int JAC_MAX_SWEEPS = 30;
 // scratch of the reduction-route eigen-solver (k_tridiag.hip)
 // doubles per matrix behind the n^2 of Z2: the 16 x 16 T factors of the blocked back-transformation, ceil((n - 2) / 16) of them
 #define MOPT_TRI_T_DOUBLES(n) ((size_t)16 * ((size_t)(n) + 16))
-struct TriScratch { double *D, *E, *TAU, *WT, *onenrm, *Z2; int *bstart, *bend, *cstart, *ncl, *fail; };
+struct TriScratch { double *D, *E, *TAU, *WT, *onenrm, *Z2; int *bstart, *bend, *cstart, *ncl, *fail, *defl; };      // defl: [batch] where the tridiagonalisation stopped early (0: ran to the end)
 
 // Device workspace of one batched RSIRFO.run (all pointers are device pointers).
 struct RsirfoWork {
@@ -33,6 +33,8 @@ struct RsirfoWork {
     mopt_rsirfo_params *params = nullptr;
     mopt_rsirfo_state *states = nullptr;
     TriScratch tri = {};
+    int defl_hint = -1;           // tridiagonalisation with the deflation test: 0 never (the caller knows the matrices are dense), 1 / -1 yes, unless the
+                                  // outcomes of the last solves say otherwise (DeflProbe, k_tridiag.hip)
     // debug mode (mopt_debug_poison): every array of the block is preceded and followed by a guard gap filled with MOPT_CANARY_BYTE and is
     // itself filled with 0xFF bytes (a NaN as a double, -1 as an int) -- an out-of-bounds write damages a gap, a read of memory nobody
     // wrote shows up as NaN in the results.  check_canaries returns MOPT_E_STATE and names the array in front of the first damaged gap.
@@ -115,7 +117,7 @@ bool mopt_apply_qt_supported(int n);
 int mopt_launch_apply_qt(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_A, const double *d_T, const double *d_in, double *d_out);
 int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, double *d_Vt, double *d_D, double *d_E, double *d_TAU,
                              double *d_WT, double *d_onenrm, int *d_bstart, int *d_bend, int *d_cstart, int *d_ncl, int *d_fail,
-                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook = nullptr, int *d_sticky = nullptr);
+                             double *d_W, int *d_perm, int *d_info, double *d_Z2, EighRfoHook *hook = nullptr, int *d_sticky = nullptr, int *d_defl = nullptr, int defl_hint = -1);
 // algorithm switch: 0 = block Jacobi (k_eigh.hip), 1 = tridiagonal reduction route (k_tridiag.hip); env MOPT_EIGH_ALGO overrides
 int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, bool preserve_A = true, EighRfoHook *hook = nullptr);
 int mopt_eigh_algo(int n);   // 1 = reduction route (k_tridiag.hip), 0 = one-sided Jacobi (k_eigh.hip)

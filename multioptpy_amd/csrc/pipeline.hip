@@ -5,6 +5,7 @@
 RsirfoWork::~RsirfoWork() {
     // (the sentinel bookkeeping of k_tri_early is per address: memory that goes back to the allocator is not "known clean" any more)
     if (ctx && block && ctx->early_clean == (const void *)tri.D) ctx->early_clean = nullptr;
+    if (ctx && block && ctx->defl.key == (const void *)tri.D) { ctx->defl.key = nullptr; ctx->defl.skip_left = 0; ctx->defl.dense_streak = 0; }
     if (block) hipFree(block);
 }
 
@@ -69,6 +70,7 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
     want(&tri.ncl, (size_t)2 * batch * 4, "tri.ncl"); want(&tri.fail, (size_t)batch * 4, "tri.fail");
     want(&tri.Z2, (size_t)batch * ((size_t)n * n + MOPT_TRI_T_DOUBLES(n)) * 8, "tri.Z2");     // Loewdin scratch + T factors
     want(&sticky, 4, "sticky");
+    want(&tri.defl, (size_t)batch * 4, "tri.defl");
     size_t tot = gap;
     for (auto &it : items) { it.off = tot; tot += al(it.bytes) + gap; }
     if (hipMalloc(&block, tot) != hipSuccess) { c->err = "hipMalloc failed (RSIRFO workspace)"; block = nullptr; return MOPT_E_NOMEM; }
@@ -83,7 +85,7 @@ int RsirfoWork::alloc(mopt_ctx *c, int n_, int batch_, bool own_hessian, bool wi
         gaps.emplace_back(0, gap); gap_names.push_back("(start of block)");
         for (auto &it : items) { gaps.emplace_back(it.off + it.bytes, al(it.bytes) - it.bytes + gap); gap_names.push_back(it.name); }      // (alignment slack included)
     }
-    if (hipMemsetAsync(sticky, 0, 4, c->stream) != hipSuccess) { c->err = "hipMemset failed (workspace)"; return MOPT_E_DEVICE; }
+    if (hipMemsetAsync(sticky, 0, 4, c->stream) != hipSuccess || hipMemsetAsync(tri.defl, 0, (size_t)batch * 4, c->stream) != hipSuccess) { c->err = "hipMemset failed (workspace)"; return MOPT_E_DEVICE; }
     return MOPT_OK;
 }
 
@@ -168,7 +170,7 @@ int mopt_rsirfo_retry_timeouts(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, 
         v.coef += b; v.params += b; v.states += b;
         v.tri.D += (size_t)b * n; v.tri.E += (size_t)b * n; v.tri.TAU += (size_t)b * n; v.tri.WT += (size_t)b * n; v.tri.onenrm += (size_t)b * n;
         v.tri.bstart += (size_t)b * n; v.tri.bend += (size_t)b * n; v.tri.cstart += (size_t)2 * b * n; v.tri.ncl += 2 * b; v.tri.fail += b;
-        v.tri.Z2 += (size_t)b * (nn + MOPT_TRI_T_DOUBLES(n));
+        v.tri.Z2 += (size_t)b * (nn + MOPT_TRI_T_DOUBLES(n)); v.tri.defl += b;
         ctx->tri_no_persist = true;
         rc = mopt_launch_project_hess(ctx, n, 1, d_Hsym + b * nn, v.Bias, v.x, v.Q, v.W6, v.A, /*basis_ready=*/true);
         if (rc == MOPT_OK) rc = mopt_eigh_auto(ctx, v, n, 1, false, /*preserve_A=*/false, nullptr);
@@ -196,7 +198,7 @@ int mopt_eigh_auto(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool warm, b
             work = wk.Gt;
         }
         return mopt_launch_eigh_tridiag(ctx, n, batch, work, wk.Vt, wk.tri.D, wk.tri.E, wk.tri.TAU, wk.tri.WT, wk.tri.onenrm, wk.tri.bstart,
-                                        wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo, wk.tri.Z2, hook, wk.sticky);
+                                        wk.tri.bend, wk.tri.cstart, wk.tri.ncl, wk.tri.fail, wk.eigw, wk.perm, wk.einfo, wk.tri.Z2, hook, wk.sticky, wk.tri.defl, wk.defl_hint);
     }
     return mopt_launch_eigh(ctx, n, batch, wk.A, wk.sigma, wk.Gt, wk.Vt, wk.rotcount, wk.eigw, wk.perm, wk.einfo, MOPT_DEFAULT_SWEEPS, warm);
 }
