@@ -356,11 +356,25 @@ int mopt_keep_pot(mopt_ctx *ctx, int N, const double *X, int npairs, const int *
  * Schlegel's element code (row of his B table as schlegel.py:27-63 assigns it, + 8 for hydrogen) or, for MOPT_MODEL_MORSE, the GNB radius.
  * d3: {s6, s8, a1, a2}.
  * project = 0 skips the TR/rot projection.  H: batch x 3N x 3N. */
-enum { MOPT_MODEL_FISCHERD3OLD = 0, MOPT_MODEL_FISCHERD3 = 1, MOPT_MODEL_FISCHER = 2, MOPT_MODEL_SCHLEGEL = 3, MOPT_MODEL_MORSE = 4 };
+enum { MOPT_MODEL_FISCHERD3OLD = 0, MOPT_MODEL_FISCHERD3 = 1, MOPT_MODEL_FISCHER = 2, MOPT_MODEL_SCHLEGEL = 3, MOPT_MODEL_MORSE = 4,
+       MOPT_MODEL_LINDH2007D3 = 5 };
 int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H);
+/* The same with the two things ApproxHessian.main hands on besides the geometry (approx_hessian.py:30-112):
+ *   MOPT_MODEL_LINDH2007D3   Lindh2007D3ApproxHessian.main (ModelHessian/lindh2007d3.py:777-822), also the dispatcher's fall-back for names it does
+ *                            not know (approx_hessian.py:88-91): stretch of every pair, bend of every triple, torsion and out-of-plane term of
+ *                            every quadruple (no connectivity), the reference's triangle-wise accumulation and mirroring rule (:803-808), TR/rot
+ *                            projection, then H = V |lambda| 0.1 exp(-|g|^2) V^T.  par: the UFF van-der-Waals distance (bohr, UFF_VDW_distance_lib
+ *                            / bohr2angstroms) in the van-der-Waals slot, the element group of select_idx (:60-82; 0, 1, 2) in the model-specific slot.
+ *   G       batch x N x 3 Cartesian gradients (only the Lindh model reads them; NULL = zero)
+ *   flags   MOPT_MODEL_FLAG_CLIP: the `clip` modifier (approx_hessian.py:104-120): eigenvalues |l| >= 1 become sign(l) (2 - |l|^-0.1) */
+enum { MOPT_MODEL_FLAG_CLIP = 1 };
+int mopt_model_hessian_ex(mopt_ctx *ctx, int kind, int flags, int N, int batch, const double *X, const double *par, const double *d3, const double *G,
+                          int project, double *H);
 /* The same for the owned images of a band, from the geometries last uploaded, straight into the band's Hessians in HBM
  * (the reference recomputes the model every -mfc band steps and hands it over in tmp_hessian_{i}.npy, neb.py:515-523). */
 int mopt_band_model_hessian(mopt_band *band, int kind, const double *par, const double *d3);
+/* (with flags as mopt_model_hessian_ex; the Lindh model takes the gradients last uploaded) */
+int mopt_band_model_hessian_ex(mopt_band *band, int kind, int flags, const double *par, const double *d3);
 
 /* ---- image-sharded band and its exchange layer ------------------------------------------
  * One image block per GPU: rank r of R owns images [r I / R, (r + 1) I / R) -- their Hessians, RSIRFO instances

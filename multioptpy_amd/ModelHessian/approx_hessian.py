@@ -4,7 +4,11 @@
 substring.  On the device (``mopt_model_hessian`` of include/mopt_hip.h): the Fischer + D3 model the reference's ``-modelhess``
 switch selects by default (``fischerd3old``, interface.py:325-330; ModelHessian/fischerd3old.py:355-381), the Fischer model with
 coordination-number scaled D3 pairs (``fischerd3``, ModelHessian/fischerd3.py:177-304), the plain Fischer model (``fischer``,
-ModelHessian/fischer.py:216-236) and Schlegel's model (``schlegel``, ModelHessian/schlegel.py:66-144).  Other model names raise NotImplementedError; there is no CPU fallback.
+ModelHessian/fischer.py:216-236), Schlegel's model (``schlegel``, ModelHessian/schlegel.py:66-144), the Morse model (``morse``,
+ModelHessian/morse.py:50-106) and Lindh's 2007 model with D3 dispersion (``lindh2007d3``, ModelHessian/lindh2007d3.py:777-822) -- which is
+also what a name the dispatcher does not know falls back to, as in the reference (approx_hessian.py:88-91) -- and the ``clip`` modifier
+(approx_hessian.py:104-120).  The Swart, Lindh-1995 / -D2 / -D4, Schlegel-D3/D4, Fischer-D4 and GFN models and the ``ts`` / ``sr``
+modifiers raise NotImplementedError; there is no CPU fallback.
 
 Per-element parameters (covalent radii, C6, van-der-Waals radii, r4/r2, D3 scaling) are the numbers the reference's
 ``multioptpy/Parameters`` functions return, kept as data in ``element_tables.json`` (tools/extract_element_tables.py)."""
@@ -17,7 +21,8 @@ import numpy as np
 from .. import _lib
 from .._lib import lib, check, f64, ptr
 
-MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER, MODEL_SCHLEGEL, MODEL_MORSE = 0, 1, 2, 3, 4
+MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER, MODEL_SCHLEGEL, MODEL_MORSE, MODEL_LINDH2007D3 = 0, 1, 2, 3, 4, 5
+FLAG_CLIP = 1
 _TAB = None
 
 
@@ -37,29 +42,45 @@ def _schlegel_code(e, order):
     return row + (8 if e == "H" else 0)
 
 
+def _lindh_group(e, order):
+    """select_idx of the Lindh models (lindh2007d3.py:60-82): H -> 0, atomic numbers 2 .. 9 -> 1, everything else -> 2"""
+    z = order.index(e) + 1
+    return 0 if z < 2 else (1 if z < 10 else 2)
+
+
 def element_parameters(element_list, kind=MODEL_FISCHERD3OLD):
     """(par, d3): par = [cov | c6 | vdw | r4r2 | refcn | model-specific] as one (6 N,) array, d3 = (s6, s8, a1, a2) -- the arguments
-    of the C ABI; the last array is Schlegel's element code, or the GNB radius for the Morse model."""
+    of the C ABI; the last array is Schlegel's element code, the GNB radius for the Morse model or the element group of the Lindh model
+    (whose van-der-Waals slot carries the UFF distance)."""
     t = _tables()
     el = t["elements"]
+
+    def last(e):
+        if kind == MODEL_MORSE:
+            return el[e]["gnb"]
+        if kind == MODEL_LINDH2007D3:
+            return _lindh_group(e, t["order"])
+        return _schlegel_code(e, t["order"])
+    keys = ("cov", "c6", "uffvdw" if kind == MODEL_LINDH2007D3 else "vdw", "r4r2", "refcn")
     try:
-        par = np.concatenate([np.array([el[str(e)][k] for e in element_list], dtype=np.float64) for k in ("cov", "c6", "vdw", "r4r2", "refcn")]
-                             + [np.array([(el[str(e)]["gnb"] if kind == MODEL_MORSE else _schlegel_code(str(e), t["order"])) for e in element_list],
-                                         dtype=np.float64)])
+        cols = [[el[str(e)][k] for e in element_list] for k in keys] + [[last(str(e)) for e in element_list]]
+        if any(v is None for c in cols for v in c):
+            raise KeyError(next(str(e) for e in element_list if any(el[str(e)][k] is None for k in keys)))
+        par = np.concatenate([np.array(c, dtype=np.float64) for c in cols])
     except KeyError as e:
         raise KeyError(f"no model-Hessian parameters for element {e}") from None
     d3 = np.array([t["d3"][k] for k in ("s6", "s8", "a1", "a2")], dtype=np.float64)
     return np.ascontiguousarray(par), d3
 
 
-def model_kind(approx_hess_type):
-    """The reference's substring dispatch (approx_hessian.py:35-97), restricted to what runs on the device."""
+def model_kind(approx_hess_type, with_flags=False):
+    """The reference's substring dispatch (approx_hessian.py:35-110), restricted to what runs on the device.  with_flags: (kind, flags)."""
     name = str(approx_hess_type).lower()
     if "gfnff" in name or "gfn0xtb" in name:
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device")
     # the reference tests the substrings in this order (approx_hessian.py:41-91): fischerd3old, fischerd3, fischerd4, schlegel*, swart*,
-    # lindh*, fischer, morse
-    kind, base = None, None
+    # lindh2007d3, lindh2007d4, lindh2007, lindh, fischer, morse; anything else: Lindh (2007) D3
+    kind, base = None, ""
     if "fischerd3old" in name:
         kind, base = MODEL_FISCHERD3OLD, "fischerd3old"
     elif "fischerd3" in name:
@@ -68,18 +89,28 @@ def model_kind(approx_hess_type):
         pass
     elif "schlegel" in name:
         kind, base = MODEL_SCHLEGEL, "schlegel"
-    elif any(k in name for k in ("swart", "lindh")):
+    elif "swart" in name:
+        pass
+    elif "lindh2007d3" in name:
+        kind, base = MODEL_LINDH2007D3, "lindh2007d3"
+    elif "lindh" in name:
         pass
     elif "fischer" in name:
         kind, base = MODEL_FISCHER, "fischer"
     elif "morse" in name:
         kind, base = MODEL_MORSE, "morse"
+    else:
+        kind = MODEL_LINDH2007D3                              # "Approximate Hessian type not recognized. Using default Lindh (2007) D3 model..."
     if kind is None:
-        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, fischer, schlegel, morse)")
-    for suffix in ("ts", "sr", "clip"):                  # approx_hessian.py:93-110: modifiers applied after the model
-        if suffix in name.replace(base, ""):
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, "
+                                  "fischer, schlegel, morse, lindh2007d3)")
+    flags = 0
+    for suffix in ("ts", "sr"):                          # approx_hessian.py:93-102: modifiers applied after the model (the tests see the whole name)
+        if suffix in name:
             raise NotImplementedError(f"model Hessian modifier '{suffix}' is not available on the device")
-    return kind
+    if "clip" in name:
+        flags |= FLAG_CLIP
+    return (kind, flags) if with_flags else kind
 
 
 class ApproxHessian:
@@ -87,22 +118,24 @@ class ApproxHessian:
         self.device = device
 
     def main(self, coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
-        kind = model_kind(approx_hess_type)
+        kind, flags = model_kind(approx_hess_type, with_flags=True)
         X = f64(coord).reshape(-1, 3)
         N = X.shape[0]
         par, d3 = element_parameters(element_list, kind)
+        G = None if cart_gradient is None else f64(cart_gradient).reshape(-1, 3)
         H = np.empty((3 * N, 3 * N))
         c = _lib.ctx(self.device)
-        check(lib().mopt_model_hessian(c, kind, N, 1, ptr(X), ptr(par), ptr(d3), 1, ptr(H)), c)
+        check(lib().mopt_model_hessian_ex(c, kind, flags, N, 1, ptr(X), ptr(par), ptr(d3), ptr(G), 1, ptr(H)), c)
         return H
 
-    def batch(self, coords, element_list, approx_hess_type="fischerd3old", project=True):
+    def batch(self, coords, element_list, approx_hess_type="fischerd3old", project=True, cart_gradients=None):
         """All images of a band in one call: coords (I, N, 3) bohr -> (I, 3N, 3N)."""
-        kind = model_kind(approx_hess_type)
+        kind, flags = model_kind(approx_hess_type, with_flags=True)
         X = f64(coords)
         I, N = X.shape[0], X.shape[1]
         par, d3 = element_parameters(element_list, kind)
+        G = None if cart_gradients is None else f64(cart_gradients).reshape(I, N, 3)
         H = np.empty((I, 3 * N, 3 * N))
         c = _lib.ctx(self.device)
-        check(lib().mopt_model_hessian(c, kind, N, I, ptr(X), ptr(par), ptr(d3), 1 if project else 0, ptr(H)), c)
+        check(lib().mopt_model_hessian_ex(c, kind, flags, N, I, ptr(X), ptr(par), ptr(d3), ptr(G), 1 if project else 0, ptr(H)), c)
         return H

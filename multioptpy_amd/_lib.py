@@ -81,6 +81,8 @@ def _proto(lib):
     if hasattr(lib, "mopt_model_hessian"):
         lib.mopt_model_hessian.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, C.c_int, DP]
         lib.mopt_band_model_hessian.argtypes = [vp, C.c_int, DP, DP]
+        lib.mopt_model_hessian_ex.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, DP, DP, DP, DP, C.c_int, DP]
+        lib.mopt_band_model_hessian_ex.argtypes = [vp, C.c_int, C.c_int, DP, DP]
     if hasattr(lib, "mopt_halo_exchange"):
         lib.mopt_comm_unique_id.argtypes = [vp, C.c_int]
         lib.mopt_comm_create_rccl_rank.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
@@ -129,6 +131,22 @@ def ctx(device=None):
             _ctx[device] = h
         c = h
     return c
+
+
+def _drain():
+    """Interpreter exit: let every context's streams run dry before the HIP runtime is torn down (asynchronous bookkeeping copies of the
+    library may still be in flight; objects with __del__ -- bands, communicators -- are destroyed afterwards, against live contexts)."""
+    if _lib is None:
+        return
+    for c in list(_ctx.values()):
+        try:
+            _lib.mopt_ctx_sync(c)
+        except Exception:
+            pass
+
+
+import atexit  # noqa: E402
+atexit.register(_drain)
 
 
 def check(rc, c=None):

@@ -58,9 +58,9 @@ class Band:
         """Replace the Hessians of the owned images by the model Hessian of the geometries last uploaded, on the device
         (neb.py:515-523 with the tmp_hessian_i.npy hand-over removed)."""
         from .ModelHessian.approx_hessian import element_parameters, model_kind
-        kind = model_kind(approx_hess_type)
+        kind, flags = model_kind(approx_hess_type, with_flags=True)
         par, d3 = element_parameters(element_list, kind)
-        check(lib().mopt_band_model_hessian(self._h, kind, ptr(par), ptr(d3)), self._ctx)
+        check(lib().mopt_band_model_hessian_ex(self._h, kind, flags, ptr(par), ptr(d3)), self._ctx)
 
     def attach(self, comm):
         """Join an exchange group (multioptpy_amd.parallel): this band must own the rank's image block."""

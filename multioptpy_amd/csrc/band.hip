@@ -615,19 +615,26 @@ extern "C" int mopt_band_step(mopt_band *b, int optimize_num) {
 
 // Model Hessians of the owned images from the uploaded geometries, written straight into the band's device-resident Hessians
 // (the reference computes ApproxHessian().main per image every -mfc steps and passes it through tmp_hessian_i.npy, neb.py:515-523).
-extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par, const double *d3) {
+extern "C" int mopt_band_model_hessian_ex(mopt_band *b, int kind, int flags, const double *par, const double *d3) {
     if (!b || !par || !d3) return MOPT_E_ARG;
     mopt_ctx *ctx = b->ctx;
-    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_MORSE) { ctx->err = "mopt_band_model_hessian: unknown model"; return MOPT_E_ARG; }
+    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_LINDH2007D3) { ctx->err = "mopt_band_model_hessian: unknown model"; return MOPT_E_ARG; }
     if (!b->uploaded) { ctx->err = "mopt_band_model_hessian: no geometries uploaded"; return MOPT_E_STATE; }
     hipSetDevice(ctx->device);
     double *d_par = nullptr;
     MOPT_HIP_TRY(ctx, hipMalloc((void **)&d_par, (size_t)6 * b->N * 8));
     hipError_t e = hipMemcpyAsync(d_par, par, (size_t)6 * b->N * 8, hipMemcpyHostToDevice, ctx->stream);
-    int rc = (e == hipSuccess) ? mopt_launch_model_hessian(ctx, kind, b->N, b->count, b->X + (size_t)b->first * b->n, d_par, d3, b->wk.Gt, b->wk.Q, b->wk.W6, b->wk.H, true)
-                               : MOPT_E_DEVICE;
-    // the projection's rank-12 correction is symmetric only up to rounding (a q w + w q pair is folded into an FMA): one in-place
-    // 0.5 (H + H^T) makes the resident matrices bitwise symmetric -- what an upload of the same matrices would store, see mopt_band_set_hessian
+    int rc = MOPT_E_DEVICE;
+    const double *Xown = b->X + (size_t)b->first * b->n;
+    if (e == hipSuccess) {
+        if (kind == MOPT_MODEL_LINDH2007D3)                  // (its eigenvalue scale takes the gradient of each image: the ones last uploaded)
+            rc = mopt_lindh2007d3_full(ctx, b->N, b->count, Xown, d_par, d3, b->G + (size_t)b->first * b->n, b->wk, b->wk.H);
+        else
+            rc = mopt_launch_model_hessian(ctx, kind, b->N, b->count, Xown, d_par, d3, b->wk.Gt, b->wk.Q, b->wk.W6, b->wk.H, true);
+    }
+    if (rc == MOPT_OK && (flags & MOPT_MODEL_FLAG_CLIP)) rc = mopt_model_hessian_clip(ctx, b->n, b->count, b->wk, b->wk.H);
+    // the projection's rank-12 correction (and V f(L) V^T) is symmetric only up to rounding: one in-place 0.5 (H + H^T) makes the resident
+    // matrices bitwise symmetric -- what an upload of the same matrices would store, see mopt_band_set_hessian
     if (rc == MOPT_OK) rc = mopt_launch_sym_add(ctx, b->n, b->count, b->wk.H, nullptr, b->wk.H);
     hipStreamSynchronize(ctx->stream);
     hipFree(d_par);
@@ -636,6 +643,8 @@ extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par
     b->H_sym.assign((size_t)b->count, 1);
     return rc;
 }
+
+extern "C" int mopt_band_model_hessian(mopt_band *b, int kind, const double *par, const double *d3) { return mopt_band_model_hessian_ex(b, kind, 0, par, d3); }
 
 // Inputs of the owned images only (image-sharded band): X_own, G_own: count x N x 3, E_own: count.  The neighbours' boundary images
 // and the other ranks' energies arrive through mopt_halo_exchange.

@@ -20,6 +20,7 @@
 #include "pipeline.h"
 #include "dc_logic.h"
 #include "ql_block.hpp"
+#include "dc_red.hpp"
 
 namespace mopt {
 
@@ -34,43 +35,6 @@ struct DcPtrs {
     double *dl, *wv, *wh, *rhom;  // [B][n] merge-local at offset s: poles, weights, Loewner weights; rhom[s] = 2 |rho|
     int *nd, *ndp, *dfl, *pos, *meta;   // [B][n] merge-local; meta[s] = k, meta[s+1] = upper-only count, meta[s+2] = mixed count
     double *S, *U;                // [B][n][n]
-};
-
-struct DcWaveRed {
-    template <int K, class F> __device__ void sumk(int m, F f, double (&out)[K]) const {
-        double acc[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = 0.0;
-        for (int i = threadIdx.x & 63; i < m; i += WAVE) f(i, acc);
-#pragma unroll
-        for (int q = 0; q < K; ++q) out[q] = wave_sum(acc[q]);
-    }
-    template <class F> __device__ void for_each(int m, F f) const { for (int i = threadIdx.x & 63; i < m; i += WAVE) f(i); }
-    __device__ void sync() const { __syncthreads(); }       // (64-thread workgroups: a wave-level sync)
-};
-
-// sum over the 16 lanes of a DPP row, returned to all of them (quad permutes, half-row mirror, row mirror)
-__device__ __forceinline__ double dc_row16_sum(double v) {
-    v += dpp_f64z<0xB1>(v);
-    v += dpp_f64z<0x4E>(v);
-    v += dpp_f64z<0x141>(v);
-    v += dpp_f64z<0x140>(v);
-    return v;
-}
-// Reducer over a 16-lane group: four secular roots per wave.  The groups of a wave diverge (different iteration counts); all
-// cross-lane traffic stays inside a row, LDS accesses of one wave are served in program order, so sync() only has to stop the
-// compiler from moving LDS accesses across it.
-struct DcRow16Red {
-    template <int K, class F> __device__ void sumk(int m, F f, double (&out)[K]) const {
-        double acc[K];
-#pragma unroll
-        for (int q = 0; q < K; ++q) acc[q] = 0.0;
-        for (int i = threadIdx.x & 15; i < m; i += 16) f(i, acc);
-#pragma unroll
-        for (int q = 0; q < K; ++q) out[q] = dc_row16_sum(acc[q]);
-    }
-    template <class F> __device__ void for_each(int m, F f) const { for (int i = threadIdx.x & 15; i < m; i += 16) f(i); }
-    __device__ void sync() const { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 };
 
 __device__ __forceinline__ double dc_rsqrt(double w) {      // 1/sqrt(w), w > 0 normal: hardware estimate + two Newton steps

@@ -1846,14 +1846,15 @@ __global__ void __launch_bounds__(MAXM * 2) k_tri_small(int n, const double *__r
 // max-norm for the iteration.  Same contract as k_tri_small: WT[s .. t) and rows s .. t-1 of Zt (zero outside the block).
 __global__ void __launch_bounds__(64) k_tri_ql32(int n, const double *__restrict__ D_, const double *__restrict__ E_, const int *__restrict__ bstart_,
                                                  const int *__restrict__ bend_, double *__restrict__ WT_, double *__restrict__ Zt_, int *__restrict__ fail_,
-                                                 const int *__restrict__ dcflag_, const double *__restrict__ stage_, const int *__restrict__ early_, int early_dbg) {
+                                                 const int *__restrict__ dcflag_, const double *__restrict__ stage_, const int *__restrict__ early_, int early_dbg,
+                                                 int mmax_ql) {
     __shared__ double Zs[32 * 32];
     if (dcflag_ && dcflag_[blockIdx.y]) return;
     const int b = blockIdx.y, i0 = blockIdx.x, lane = threadIdx.x;
     const int *bstart = bstart_ + (size_t)b * n, *bend = bend_ + (size_t)b * n;
     if (bstart[i0] != i0) return;
     const int s = i0, t = bend[i0], m = t - s;
-    if (m < 2 || m > 32) return;
+    if (m < 2 || m > 32 || m > mmax_ql) return;              // (larger blocks: k_dc_block, k_dcblock.hip)
     const double *D = D_ + (size_t)b * n + s, *E = E_ + (size_t)b * n + s;
     double d, sc = 1.0;
     if (early_ && s == 0 && early_[b] == m) {
@@ -2312,6 +2313,9 @@ int mopt_tri_tail_max();
 int mopt_launch_tri_tail(mopt_ctx *ctx, hipStream_t st, int n, int K, int batch, double *d_A, double *d_D, double *d_E, double *d_TAU,
                          long long *d_prof = nullptr, const unsigned long long *d_defl = nullptr, size_t defl_stride = 0);
 size_t mopt_dc_scratch_bytes(int n, int batch);
+int mopt_dc_block_max();
+int mopt_launch_dc_block(mopt_ctx *ctx, hipStream_t st, int n, int batch, int mmin, int mmax, const double *d_D, const double *d_E, const int *d_bstart,
+                         const int *d_bend, double *d_WT, double *d_Zt, int *d_fail, const int *d_dcflag, const double *d_stage, const int *d_early);
 int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_D, const double *d_E, int *d_flag, double *d_WT,
                    double *d_Vt, double *d_Z2, int *d_bstart, int *d_bend, int *d_fail, void *scratch);
 
@@ -2711,7 +2715,12 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     // (default 32 since the end of round 2: a 33..64-row block costs the two-wave Jacobi k_tri_small<64,33> 0.37 ms (33 rows) to 0.8 ms
     // (50 rows) against ~0.15 ms for the chain -- single 33 x 33 Hessian 0.74 -> 0.53 ms per RSIRFO.run, 60-step average of the headline
     // band 1.31 -> 1.12 ms; MOPT_TRI_DCMIN=64 restores the old split and keeps the Jacobi instantiation under test)
-    const int dc_min = (tri_env("MOPT_TRI_DC") && atoi(tri_env("MOPT_TRI_DC")) == 0) ? 0 : (tri_env("MOPT_TRI_DCMIN") ? atoi(tri_env("MOPT_TRI_DCMIN")) : 32);
+    // Round 3: unreduced blocks of dcb_lo .. dcb_hi rows are solved whole inside one workgroup (k_dcblock.hip: the same divide and conquer with
+    // everything in LDS), so only matrices with a block of more than dcb_hi = 72 rows take the launch-per-stage chain, and the one-wave QL is left
+    // with the blocks below dcb_lo = 13 rows.  MOPT_DCB=0 restores the round-2 split (QL up to 32 rows, chain above).
+    const bool dcb_on = !(tri_env("MOPT_DCB") && atoi(tri_env("MOPT_DCB")) == 0);
+    const int dcb_lo = tri_env("MOPT_DCB_LO") ? atoi(tri_env("MOPT_DCB_LO")) : 13, dcb_hi = mopt_dc_block_max();
+    const int dc_min = (tri_env("MOPT_TRI_DC") && atoi(tri_env("MOPT_TRI_DC")) == 0) ? 0 : (tri_env("MOPT_TRI_DCMIN") ? atoi(tri_env("MOPT_TRI_DCMIN")) : (dcb_on ? dcb_hi : 32));
     int *d_dcflag = nullptr;
     if (dc_min > 0 && n > dc_min) {
         const size_t need = 256 + mopt_dc_scratch_bytes(n, batch) + (size_t)batch * 4;
@@ -2725,8 +2734,9 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         }
         d_dcflag = (int *)((char *)ctx->arena + 256 + mopt_dc_scratch_bytes(n, batch));
     }
-    int small_max = tri_env("MOPT_TRI_SMALL") ? atoi(tri_env("MOPT_TRI_SMALL")) : TRI_SMALL;            // 0 disables the small-block solver
-    if (small_max > TRI_SMALL) small_max = TRI_SMALL;
+    const int small_cap = dcb_on ? dcb_hi : TRI_SMALL;
+    int small_max = tri_env("MOPT_TRI_SMALL") ? atoi(tri_env("MOPT_TRI_SMALL")) : small_cap;            // 0 disables the small-block solvers
+    if (small_max > small_cap) small_max = small_cap;
     if (small_max < 0) small_max = 0;
     // (Both chains -- bisection / inverse iteration on the main stream, divide and conquer on its helper stream -- are enqueued on every
     // call, each kernel skipping the matrices of the other chain.  Skipping the idle D&C chain on the strength of the previous call's
@@ -2767,10 +2777,14 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             const bool use_ql = !(tri_env("MOPT_TRI_QL") && atoi(tri_env("MOPT_TRI_QL")) == 0);
             if (small_max > 0 && use_ql)
                 hipLaunchKernelGGL(k_tri_ql32, dim3(n, batch), dim3(64), 0, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag,
-                                   (const double *)early_stage, (const int *)early_flag, tri_env("MOPT_TRI_EARLYDBG") ? 1 : 0);
+                                   (const double *)early_stage, (const int *)early_flag, tri_env("MOPT_TRI_EARLYDBG") ? 1 : 0, dcb_on ? dcb_lo - 1 : 32);
             else if (small_max > 0)
                 hipLaunchKernelGGL((k_tri_small<32, 2>), dim3(n, batch), dim3(64), (size_t)2 * 32 * 33 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
-            if (small_max > 32)
+            if (dcb_on && small_max >= dcb_lo) {
+                const int rc = mopt_launch_dc_block(ctx, ctx->side, n, batch, dcb_lo, small_max, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag,
+                                                    (const double *)early_stage, (const int *)early_flag);
+                if (rc != MOPT_OK) return rc;
+            } else if (small_max > 32)
                 hipLaunchKernelGGL((k_tri_small<64, 33>), dim3(n, batch), dim3(128), (size_t)2 * 64 * 65 * 8, ctx->side, n, d_D, d_E, d_bstart, d_bend, d_WT, d_Vt, d_fail, (const int *)d_dcflag);
             MOPT_HIP_TRY(ctx, hipEventRecord(ctx->ev_join4, ctx->side));
         }

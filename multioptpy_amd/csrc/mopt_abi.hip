@@ -96,6 +96,8 @@ void pin_release(mopt_ctx *ctx) {
 void *mopt_pin_get(mopt_ctx *ctx, size_t bytes) { return pin_get_impl(ctx, bytes); }
 
 
+void mopt_ws_release(mopt_ctx *ctx);
+
 extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     if (!ctx) return MOPT_E_ARG;
     hipSetDevice(ctx->device);
@@ -110,6 +112,7 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipStreamSynchronize(ctx->side3);
     hipEventDestroy(ctx->ev_fork5); hipEventDestroy(ctx->ev_join5);
     hipEventDestroy(ctx->ev_fork6); hipEventDestroy(ctx->ev_join6);
+    mopt_ws_release(ctx);
     if (ctx->early_buf) hipFree(ctx->early_buf);
     if (ctx->defl.ev) { hipEventSynchronize(ctx->defl.ev); hipEventDestroy(ctx->defl.ev); }
     if (ctx->defl.pin) hipHostFree(ctx->defl.pin);
@@ -148,6 +151,11 @@ extern "C" const char *mopt_last_error(const mopt_ctx *ctx) { return ctx ? ctx->
 extern "C" int mopt_ctx_sync(mopt_ctx *ctx) {
     if (!ctx) return MOPT_E_ARG;
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // (the helper streams are joined into the main stream by events wherever a result is needed; what may still be in flight on them
+    // is bookkeeping -- the tail of an idle divide-and-conquer chain, the read-back of the deflation outcome)
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side2));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->side3));
     return MOPT_OK;
 }
 
@@ -319,20 +327,40 @@ extern "C" int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *co
     return MOPT_OK;
 }
 
-extern "C" int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H) {
+extern "C" int mopt_model_hessian_ex(mopt_ctx *ctx, int kind, int flags, int N, int batch, const double *X, const double *par, const double *d3, const double *G,
+                                     int project, double *H) {
     if (!ctx) return MOPT_E_ARG;
-    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_MORSE) { ctx->err = "mopt_model_hessian: unknown model"; return MOPT_E_ARG; }
+    if (kind < MOPT_MODEL_FISCHERD3OLD || kind > MOPT_MODEL_LINDH2007D3) { ctx->err = "mopt_model_hessian: unknown model"; return MOPT_E_ARG; }
     if (bad_dims(ctx, 3 * N, batch) || N < 1 || !X || !par || !d3 || !H) return MOPT_E_ARG;
     hipSetDevice(ctx->device);
     const int n = 3 * N;
     const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
-    DBuf dH, dA, dX, dQ, dW, dP;
-    TRY(dH.alloc(ctx, nn)); TRY(dA.alloc(ctx, nn)); TRY(dX.alloc(ctx, nv)); TRY(dQ.alloc(ctx, 6 * nv)); TRY(dW.alloc(ctx, 6 * nv)); TRY(dP.alloc(ctx, (size_t)6 * N * 8));
+    DBuf dH, dA, dX, dQ, dW, dP, dG;
+    TRY(dA.alloc(ctx, nn)); TRY(dX.alloc(ctx, nv)); TRY(dP.alloc(ctx, (size_t)6 * N * 8));
     H2D(ctx, dX.p, X, nv); H2D(ctx, dP.p, par, (size_t)6 * N * 8);
-    TRY(mopt_launch_model_hessian(ctx, kind, N, batch, dX.as<double>(), dP.as<double>(), d3, dH.as<double>(), dQ.as<double>(), dW.as<double>(), dA.as<double>(), project != 0));
+    const bool lindh = (kind == MOPT_MODEL_LINDH2007D3), clip = (flags & MOPT_MODEL_FLAG_CLIP) != 0;
+    RsirfoWork wk;                                           // eigen-solver workspace: only the Lindh model and the clip modifier need one
+    if (lindh || clip) TRY(wk.alloc(ctx, n, batch, false, false, false));
+    if (lindh) {
+        if (G) { TRY(dG.alloc(ctx, nv)); H2D(ctx, dG.p, G, nv); }
+        TRY(mopt_lindh2007d3_full(ctx, N, batch, dX.as<double>(), dP.as<double>(), d3, G ? dG.as<double>() : nullptr, wk, dA.as<double>()));
+    } else {
+        TRY(dH.alloc(ctx, nn)); TRY(dQ.alloc(ctx, 6 * nv)); TRY(dW.alloc(ctx, 6 * nv));
+        TRY(mopt_launch_model_hessian(ctx, kind, N, batch, dX.as<double>(), dP.as<double>(), d3, dH.as<double>(), dQ.as<double>(), dW.as<double>(), dA.as<double>(), project != 0));
+    }
+    if (clip) TRY(mopt_model_hessian_clip(ctx, n, batch, wk, dA.as<double>()));
     D2H(ctx, H, dA.p, nn);
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (lindh || clip) {
+        std::vector<int> einfo((size_t)2 * batch);
+        MOPT_HIP_TRY(ctx, hipMemcpy(einfo.data(), wk.einfo, einfo.size() * sizeof(int), hipMemcpyDeviceToHost));
+        for (int b = 0; b < batch; ++b) if (einfo[2 * b + 1] & 4) { ctx->err = "mopt_model_hessian: the eigen-solver failed"; return MOPT_E_NUMERIC; }
+    }
     return MOPT_OK;
+}
+
+extern "C" int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *X, const double *par, const double *d3, int project, double *H) {
+    return mopt_model_hessian_ex(ctx, kind, 0, N, batch, X, par, d3, nullptr, project, H);
 }
 
 extern "C" int mopt_project_trrot_grad(mopt_ctx *ctx, int n, int batch, const double *g, const double *X, double *gp) {
@@ -454,6 +482,58 @@ extern "C" int mopt_neb_force(mopt_ctx *ctx, int variant, int I, int N, const do
 // ------------------------------------------------------------------------------------------
 // RSIRFO.run on host buffers
 // ------------------------------------------------------------------------------------------
+// Workspaces of the single-geometry entry points are kept per context and shape (a hipMalloc + hipFree pair per call -- the free
+// synchronises the device -- was a quarter of a 0.4 ms call at n = 33); at most four shapes, least recently used goes first.  The
+// debug mode (mopt_debug_poison) takes a fresh, poisoned and guarded workspace for every call instead.
+namespace {
+struct WsEntry { int n = 0, batch = 0, flags = 0; RsirfoWork *wk = nullptr; void *io = nullptr; size_t io_bytes = 0; unsigned long long stamp = 0; };
+std::map<mopt_ctx *, std::vector<WsEntry>> g_ws;
+std::mutex g_ws_mu;
+unsigned long long g_ws_clock = 0;
+void ws_drop(WsEntry &e) { delete e.wk; if (e.io) hipFree(e.io); e = WsEntry(); }
+}  // namespace
+void mopt_ws_release(mopt_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto it = g_ws.find(ctx);
+    if (it == g_ws.end()) return;
+    for (auto &e : it->second) ws_drop(e);
+    g_ws.erase(it);
+}
+// the workspace of shape (n, batch, own H / bias / in-place copy) and an I/O span of io_bytes; both stay owned by the cache
+static int ws_get(mopt_ctx *ctx, int n, int batch, bool own_h, bool bias, bool inplace, size_t io_bytes, RsirfoWork **wk_out, void **io_out) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    auto &v = g_ws[ctx];
+    const int flags = (own_h ? 1 : 0) | (bias ? 2 : 0) | (inplace ? 4 : 0);
+    WsEntry *hit = nullptr;
+    for (auto &e : v) if (e.wk && e.n == n && e.batch == batch && e.flags == flags) hit = &e;
+    if (!hit) {
+        if (v.size() >= 4) {
+            size_t old = 0;
+            for (size_t i = 1; i < v.size(); ++i) if (v[i].stamp < v[old].stamp) old = i;
+            hipStreamSynchronize(ctx->stream);
+            ws_drop(v[old]);
+            v.erase(v.begin() + (long)old);
+        }
+        WsEntry e;
+        e.n = n; e.batch = batch; e.flags = flags;
+        e.wk = new (std::nothrow) RsirfoWork();
+        if (!e.wk) return MOPT_E_NOMEM;
+        const int rc = e.wk->alloc(ctx, n, batch, own_h, bias, inplace);
+        if (rc != MOPT_OK) { delete e.wk; return rc; }
+        v.push_back(e);
+        hit = &v.back();
+    }
+    if (hit->io_bytes < io_bytes) {
+        if (hit->io) { hipStreamSynchronize(ctx->stream); hipFree(hit->io); }
+        hit->io = nullptr; hit->io_bytes = 0;
+        if (hipMalloc(&hit->io, io_bytes) != hipSuccess) { ctx->err = "hipMalloc failed"; return MOPT_E_NOMEM; }
+        hit->io_bytes = io_bytes;
+    }
+    hit->stamp = ++g_ws_clock;
+    *wk_out = hit->wk; *io_out = hit->io;
+    return MOPT_OK;
+}
+
 extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *params, mopt_rsirfo_state *state,
                                const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
                                const double *g, const double *pre_geom, const double *pre_g, const double *B_e, double *step,
@@ -462,9 +542,27 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
     if (!params || !state || !geom || !B_g || !B_e || !step) { ctx->err = "mopt_rsirfo_run: null argument"; return MOPT_E_ARG; }
     if (!hessian) { ctx->err = "Hessian matrix must be set before running optimization"; return MOPT_E_STATE; }
     hipSetDevice(ctx->device);
-    RsirfoWork wk;
-    TRY(wk.alloc(ctx, n, batch, /*own_hessian=*/true, bias_hessian != nullptr, H_inplace != nullptr));
     const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
+    auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    const size_t io_tot = 6 * al(nv) + al(batch * sizeof(double)) + al(batch * sizeof(mopt_rsirfo_params)) + 2 * al(batch * sizeof(int)) +
+                          al(batch * sizeof(mopt_rsirfo_state));
+    // workspace + I/O span: cached per shape, or fresh (poisoned, guarded) in the debug mode
+    RsirfoWork fresh;
+    DBuf fresh_io;
+    RsirfoWork *wkp = &fresh;
+    void *io_p = nullptr;
+    if (mopt_debug_poison_on()) {
+        TRY(fresh.alloc(ctx, n, batch, /*own_hessian=*/true, bias_hessian != nullptr, H_inplace != nullptr));
+        TRY(fresh_io.alloc(ctx, io_tot));
+        io_p = fresh_io.p;
+    } else {
+        TRY(ws_get(ctx, n, batch, true, bias_hessian != nullptr, H_inplace != nullptr, io_tot, &wkp, &io_p));
+    }
+    RsirfoWork &wk = *wkp;
+    // (the cached object keeps its own array pointers: the fields redirected into the I/O span below are restored on every exit)
+    struct Restore { RsirfoWork &w; double *x, *bg, *g, *px, *pg, *be, *step; mopt_rsirfo_params *params; int *rules, *do_update; mopt_rsirfo_state *states;
+                     ~Restore() { w.x = x; w.bg = bg; w.g = g; w.px = px; w.pg = pg; w.be = be; w.step = step; w.params = params; w.rules = rules; w.do_update = do_update; w.states = states; } }
+        restore{wk, wk.x, wk.bg, wk.g, wk.px, wk.pg, wk.be, wk.step, wk.params, wk.rules, wk.do_update, wk.states};
     const bool have_prev = pre_geom && pre_g;
     std::vector<int> rules(batch), upd(batch);
     bool any_flow = false, any_upd = false;
@@ -480,13 +578,8 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
     // synchronisation (twelve small pageable copies in and four out were 130 us of a 0.5 ms call).  The span replaces the workspace's
     // own arrays of the same names for this call (the workspace layout itself is shared with the band and stays as it is):
     //   in:  [x | bg | g | px | pg | be | params | rules | do_update | states]      out: [states | step]
-    DBuf io;
     {
-        auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
-        const size_t tot = 6 * al(nv) + al(batch * sizeof(double)) + al(batch * sizeof(mopt_rsirfo_params)) + 2 * al(batch * sizeof(int)) +
-                           al(batch * sizeof(mopt_rsirfo_state));
-        TRY(io.alloc(ctx, tot));
-        char *q = (char *)io.p;
+        char *q = (char *)io_p;
         auto take = [&](size_t bytes) { void *r = q; q += al(bytes); return r; };
         wk.x = (double *)take(nv); wk.bg = (double *)take(nv); wk.g = (double *)take(nv); wk.px = (double *)take(nv); wk.pg = (double *)take(nv);
         wk.be = (double *)take(batch * sizeof(double));

@@ -89,6 +89,10 @@ int mopt_launch_afir(mopt_ctx *ctx, int N, const double *d_x, const double *d_co
 // FischerD3ApproxHessianOld.main for a batch of geometries (k_modelhess.hip); d3 is a HOST array {s6, s8, a1, a2}
 int mopt_launch_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *d_X, const double *d_par, const double *d3, double *d_H, double *d_Q,
                               double *d_W, double *d_A, bool project);
+// Lindh2007D3 model Hessian and the `clip` modifier of ApproxHessian.main (k_lindh.hip)
+int mopt_lindh2007d3_full(mopt_ctx *ctx, int N, int batch, const double *d_X, const double *d_par, const double *d3, const double *d_g, RsirfoWork &wk,
+                          double *d_out);
+int mopt_model_hessian_clip(mopt_ctx *ctx, int n, int batch, RsirfoWork &wk, double *d_H);
 int mopt_jacobi_block_width(const mopt_ctx *ctx, int n);
 int mopt_launch_eigh(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma, double *d_Gt, double *d_Vt,
                      int *d_rotcount, double *d_W, int *d_perm, int *d_info, int max_sweeps, bool warm);

@@ -5,6 +5,8 @@
   FischerApproxHessian.main         multioptpy/ModelHessian/fischer.py:216-236        (no dispersion term)
   SchlegelApproxHessian.main        multioptpy/ModelHessian/schlegel.py:66-144        (pair springs from the connectivity tables)
   MorseApproxHessian.create_model_hessian  multioptpy/ModelHessian/morse.py:50-106    (all-pairs Morse curvature, unprojected)
+  Lindh2007D3ApproxHessian.main     multioptpy/ModelHessian/lindh2007d3.py:777-822    (all pairs / triples / quadruples, no connectivity;
+                                    the dispatcher's fall-back for unknown names, approx_hessian.py:72-74,88-91)
 with its helpers: BondConnectivity (Utils/bond_connectivity.py:7-135), stretch2 / bend2 / torsion2 (ModelHessian/calc_params.py:139-227).
 Pinned by tests/golden/g10_model_hessian.npz and g10b_model_hessian_variants.npz (outputs of the reference itself).  Coordinates in bohr."""
 import json
@@ -428,7 +430,226 @@ def morse(coord, element_list, De=0.10, a=0.20):
     return 0.5 * (H + H.T)
 
 
+# ---- Lindh2007D3ApproxHessian (lindh2007d3.py) -----------------------------------------------------------------------
+_L07_R = np.array([[1.35, 2.10, 2.53], [2.10, 2.87, 3.80], [2.53, 3.80, 4.50]])      # lindh2007d3.py:40-56 (rAv is carried but unused: the
+_L07_A = np.array([[1.0, 0.3949, 0.3949], [0.3949, 0.28, 0.12], [0.3949, 0.12, 0.06]])  # reference length is the sum of covalent radii)
+_L07_D = np.array([[0.0, 3.6, 3.6], [3.6, 5.3, 5.3], [3.6, 5.3, 5.3]])
+_L07 = dict(kr=0.45, kf=0.10, kt=0.0025, ko=0.16, kd=0.05, eps=1.0e-12)
+
+
+def lindh_group(element):
+    """select_idx (lindh2007d3.py:60-82): H -> 0, atomic numbers 2 .. 9 -> 1, everything else -> 2"""
+    z = tables()["order"].index(element) + 1
+    return 0 if z < 2 else (1 if z < 10 else 2)
+
+
+def outofplane2(x):
+    """calc_params.py:68-135: out-of-plane angle of x[3] (centre) against the plane of its three partners, as a bend over an auxiliary point"""
+    r1, r2, r3 = x[0] - x[3], x[1] - x[3], x[2] - x[3]
+    e2, e3 = r2 / np.linalg.norm(r2), r3 / np.linalg.norm(r3)
+    if abs(np.arccos(np.dot(e3, e2)) - np.pi) < 1e-12:
+        return None
+    nrm = np.cross(r2, r3)
+    if np.dot(nrm, nrm) < 1e-12:
+        return None
+    _, br = bend2(np.array([x[0], x[3], nrm + x[3]]))
+    w = br[2]
+    # bt[0] = -(w0, w1, w2); bt[1] = -(w1, w2, w0); bt[2] = -(w2, w0, w1) (the cyclic index walk of the reference), bt[3] = -(sum); then the sign flip
+    b0 = np.array([w[0], w[1], w[2]]); b1 = np.array([w[1], w[2], w[0]]); b2 = np.array([w[2], w[0], w[1]])
+    return np.array([b0, b1, b2, -(b0 + b1 + b2)])
+
+
+def _l07_pairs(coord, element_list):
+    """per pair: squared distance, distance, exponential factor exp(alpha (r_cov^2 - r^2)), D3 'force constant' beyond twice the covalent length"""
+    t = tables()
+    el = t["elements"]
+    d3 = t["d3"]
+    N = len(coord)
+    grp = [lindh_group(e) for e in element_list]
+    cov = np.array([el[e]["cov"] for e in element_list])
+    c6 = np.array([el[e]["c6"] for e in element_list])
+    r4 = np.array([el[e]["r4r2"] for e in element_list])
+    uff = np.array([el[e]["uffvdw"] for e in element_list])
+    D = coord[:, None, :] - coord[None, :, :]
+    r2 = np.sum(D * D, axis=2)
+    r = np.sqrt(r2)
+    rc = cov[:, None] + cov[None, :]
+    alpha = np.array([[_L07_A[grp[i]][grp[j]] for j in range(N)] for i in range(N)])
+    d0 = np.array([[_L07_D[grp[i]][grp[j]] for j in range(N)] for i in range(N)])
+    C6 = np.sqrt(c6[:, None] * c6[None, :])
+    C8 = 3.0 * C6 * np.sqrt(r4[:, None] * r4[None, :])
+    R0 = uff[:, None] + uff[None, :]
+    bj = (R0 + d3["a1"]) * d3["a2"]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        fd6 = r ** 6 / (r ** 6 + bj ** 6)
+        fd8 = r ** 8 / (r ** 8 + bj ** 8)
+        kd3 = -(-d3["s6"] * C6 * fd6 / r ** 6 - d3["s8"] * C8 * fd8 / r ** 8)          # calc_d3_force_const
+    far = r > 2.0 * rc
+    g = np.exp(alpha * (rc ** 2 - r2))
+    return dict(D=D, r2=r2, r=r, rc=rc, g=g, far=far, kd3=np.where(far, kd3, 0.0), d0=d0, C6=C6, C8=C8, bj=bj, d3=d3)
+
+
+def lindh2007_d3(coord, element_list, cart_gradient=None):
+    coord = np.asarray(coord, dtype=float).reshape(-1, 3)
+    N = len(coord)
+    P = _l07_pairs(coord, element_list)
+    K = _L07
+    n = 3 * N
+    # the reference accumulates bond and angle terms into the LOWER triangle, torsion and out-of-plane terms into the UPPER triangle of the
+    # off-diagonal atom blocks (and everything into the strictly lower part of the diagonal blocks), then mirrors with the rule of :803-808
+    Lo = np.zeros((n, n))
+    Up = np.zeros((n, n))
+    d3 = P["d3"]
+    # ---- bonds: every pair (lindh2007d3.py:223-303)
+    for i in range(N):
+        for j in range(i):
+            v = P["D"][i, j]
+            r2, r = P["r2"][i, j], P["r"][i, j]
+            gmm = K["kr"] * P["g"][i, j] + K["kd"] * P["kd3"][i, j]
+            blk = np.zeros((3, 3))
+            if r >= 0.1:                                   # calc_d3_gradient_components (:169-221)
+                b6, b8 = P["bj"][i, j] ** 6, P["bj"][i, j] ** 8
+                r6, r8 = r ** 6, r ** 8
+                dm6, dm8 = r6 / (r6 + b6), r8 / (r8 + b8)
+                dd6 = 6.0 * r6 * b6 / ((r6 + b6) ** 2 * r)
+                dd8 = 8.0 * r8 * b8 / ((r8 + b8) ** 2 * r)
+                force = d3["s6"] * P["C6"][i, j] * (6.0 * dm6 / r ** 7 + dd6 / r ** 6) + d3["s8"] * P["C8"][i, j] * (8.0 * dm8 / r ** 9 + dd8 / r ** 8)
+                blk = (force / r) * np.outer(v, v) / r2
+            h = gmm * np.outer(v, v) / r2 - blk
+            for a in (i, j):
+                for l in range(3):
+                    for m_ in range(l + 1):
+                        Lo[3 * a + l, 3 * a + m_] += h[l, m_]
+            Lo[3 * i:3 * i + 3, 3 * j:3 * j + 3] -= h
+    # ---- angles: vertex i, partners j > k (:305-520)
+
+    def put(a, sa, b, sb, w):
+        if a > b:
+            Lo[3 * a:3 * a + 3, 3 * b:3 * b + 3] += w * np.outer(sa, sb)
+        else:
+            Lo[3 * b:3 * b + 3, 3 * a:3 * a + 3] += w * np.outer(sb, sa)
+
+    def diag(a, sa, w):
+        for l in range(3):
+            for m_ in range(l):
+                Lo[3 * a + l, 3 * a + m_] += w * sa[l] * sa[m_]
+
+    for i in range(N):
+        for j in range(N):
+            if j == i:
+                continue
+            for k in range(j):
+                if k == i:
+                    continue
+                vij, vik = P["D"][i, j], P["D"][i, k]
+                rij, rik, rjk = P["r"][i, j], P["r"][i, k], P["r"][j, k]
+                cosang = np.dot(vij, vik) / (rij * rik)
+                if abs(cosang - 1.0) < K["eps"]:
+                    continue
+                gij = P["g"][i, j] + 0.5 * K["kd"] * P["kd3"][i, j]
+                gik = P["g"][i, k] + 0.5 * K["kd"] * P["kd3"][i, k]
+                gjk = K["kf"] * (gij + 0.5 * K["kd"] / K["kr"] * P["d0"][i, j]) * (gik + 0.5 * K["kd"] / K["kr"] * P["d0"][i, k])
+                cr = np.cross(vij, vik)
+                rc2 = np.dot(cr, cr)
+                rcross = np.sqrt(rc2) if rc2 > 1.0e-12 else 0.0
+                if rik <= K["eps"] or rij <= K["eps"] or rjk <= K["eps"]:
+                    continue
+                sint = rcross / (rij * rik)
+                if sint > K["eps"]:
+                    sj = (vij / rij * cosang - vik / rik) / (rij * sint)
+                    sk = (vik / rik * cosang - vij / rij) / (rik * sint)
+                    dirs = [(sj, sk)]
+                else:
+                    if abs(vij[1]) < K["eps"] and abs(vij[2]) < K["eps"]:
+                        p1 = np.array([-vij[1], vij[0], 0.0])
+                        p2 = np.array([-vij[0] * vij[2], -vij[1] * vij[2], vij[0] ** 2 + vij[1] ** 2])
+                    else:
+                        p1, p2 = np.array([1.0, 0.0, 0.0]), np.array([0.0, 1.0, 0.0])
+                    dirs = []
+                    for pv in (p1, p2):
+                        u = pv / np.linalg.norm(pv)
+                        dirs.append((-u / rij, -u / rik))
+                for sj, sk in dirs:
+                    si = -sj - sk
+                    put(i, si, j, sj, gjk); put(i, si, k, sk, gjk); put(j, sj, k, sk, gjk)
+                    diag(j, sj, gjk); diag(i, si, gjk); diag(k, sk, gjk)
+    # ---- torsions i-j-k-l with i < j < k < l (:522-641) and out-of-plane terms, centre i < j < k < l (:643-775)
+    cos35 = np.cos(35.0 / 180 * np.pi)
+
+    def put_up(atoms, svec, w):
+        for p in range(4):
+            for q in range(p + 1, 4):
+                a, b = atoms[p], atoms[q]
+                Up[3 * a:3 * a + 3, 3 * b:3 * b + 3] += w * np.outer(svec[p], svec[q])
+            diag(atoms[p], svec[p], w)
+
+    half = 0.5 * K["kd"] / K["kr"]
+    for j in range(N):
+        for k in range(j + 1, N):
+            for i in range(j):
+                for l in range(k + 1, N):
+                    rij, rjk, rkl = coord[i] - coord[j], coord[j] - coord[k], coord[k] - coord[l]
+                    c2 = np.dot(rij, rjk) / np.sqrt(np.dot(rij, rij) * np.dot(rjk, rjk))
+                    if abs(c2) > cos35:
+                        continue
+                    c3 = np.dot(rkl, rjk) / np.sqrt(np.dot(rkl, rkl) * np.dot(rjk, rjk))
+                    if abs(c3) > cos35:
+                        continue
+                    gij = P["g"][i, j] + 0.5 * K["kd"] * P["kd3"][i, j]
+                    gjk = P["g"][j, k] + 0.5 * K["kd"] * P["kd3"][j, k]
+                    gkl = P["g"][k, l] + 0.5 * K["kd"] * P["kd3"][k, l]
+                    tij = K["kt"] * (gij * half * P["d0"][i, j]) * (gjk * half * P["d0"][j, k]) * (gkl * half * P["d0"][k, l])
+                    bt = torsion2(coord[[i, j, k, l]])
+                    put_up((i, j, k, l), bt, tij)
+    for i in range(N):
+        for j in range(i + 1, N):
+            for k in range(j + 1, N):
+                for l in range(k + 1, N):
+                    rij, rik, ril = coord[i] - coord[j], coord[i] - coord[k], coord[i] - coord[l]
+                    nij, nik, nil = np.linalg.norm(rij), np.linalg.norm(rik), np.linalg.norm(ril)
+                    if abs(abs(np.dot(rij, rik) / (nij * nik)) - 1.0) < 0.1:
+                        continue
+                    if abs(abs(np.dot(rij, ril) / (nij * nil)) - 1.0) < 0.1:
+                        continue
+                    if abs(abs(np.dot(rik, ril) / (nik * nil)) - 1.0) < 0.1:
+                        continue
+                    tij = K["ko"] * P["g"][i, j] * P["g"][i, k] * P["g"][i, l]          # (the D3 share is switched off there: kd = 0, :734)
+                    bt = outofplane2(coord[[j, k, l, i]])
+                    if bt is None:
+                        raise FloatingPointError("degenerate out-of-plane term (the reference fails here as well)")
+                    # c[0..3] belong to (t_xyz_1..4) = (j, k, l, i); the reference names them s_i, s_j, s_k, s_l and pairs them with atoms (i, j, k, l)
+                    put_up((i, j, k, l), bt, tij)
+    # ---- mirror: a lower entry of at least 1e-10 wins over the upper one (:803-808)
+    H = np.zeros((n, n))
+    for p in range(n):
+        H[p, p] = Lo[p, p]
+        for q in range(p):
+            v = Up[q, p] if abs(Lo[p, q]) < 1.0e-10 else Lo[p, q]
+            H[p, q] = H[q, p] = v
+    Hp = pj.project_hessian_trrot(H, coord)
+    w, V = np.linalg.eigh(Hp)
+    gn = 0.0 if cart_gradient is None else np.linalg.norm(np.asarray(cart_gradient, dtype=float))
+    return (V * (np.abs(w) * 0.1 * np.exp(-gn ** 2))) @ V.T
+
+
+def smooth_eigval(w, alpha=0.1):
+    """approx_hessian.py:115-121"""
+    w = np.asarray(w, dtype=float)
+    out = w.copy()
+    m = np.abs(w) >= 1.0
+    out[m] = np.sign(w[m]) * (2.0 - 1.0 / (np.abs(w)[m] ** alpha))
+    return out
+
+
 def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
+    H = _approx_hessian_model(coord, element_list, cart_gradient, approx_hess_type)
+    if "clip" in approx_hess_type.lower():                  # approx_hessian.py:104-110
+        w, V = np.linalg.eigh(H)
+        H = V @ np.diag(smooth_eigval(w)) @ V.T
+    return H
+
+
+def _approx_hessian_model(coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
     """ApproxHessian.main: the three Fischer models are restated; the reference's substring tests come in this order
     (approx_hessian.py:35-91): gfnff, gfn0xtb, fischerd3old, fischerd3, fischerd4, schlegel*, swart*, lindh*, fischer, morse."""
     name = approx_hess_type.lower()
@@ -442,10 +663,14 @@ def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fi
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
     if "schlegel" in name:
         return schlegel(coord, element_list)
-    if any(k in name for k in ("fischerd4", "swart", "lindh")):
+    if "fischerd4" in name or "swart" in name:
+        raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
+    if "lindh2007d3" in name:
+        return lindh2007_d3(coord, element_list, cart_gradient)
+    if "lindh" in name:
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
     if "fischer" in name:
         return fischer_plain(coord, element_list)
     if "morse" in name:
         return morse(coord, element_list)
-    raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not restated by the oracle")
+    return lindh2007_d3(coord, element_list, cart_gradient)      # the dispatcher's fall-back (approx_hessian.py:88-91)

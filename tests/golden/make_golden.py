@@ -921,11 +921,32 @@ def g8_nebmain():
     _run_nebmain("f", 7, ["-ns", "9", "-p", "5"], out)                       # FIRE branch (the default optimizer of nebmain)
     _run_nebmain("s", 7, ["-ns", "6", "-p", "5", "-sd", "3", "-fe", "1"], out)     # FIRE, then steepest descent from iteration 3
     np.savez_compressed(os.path.join(HERE, "g8_nebmain.npz"), **out)
+def g10c_lindh2007d3():
+    """G10c: Lindh2007D3ApproxHessian.main (lindh2007d3.py:777-822) -- the model ApproxHessian.main falls back to for unknown names
+    (approx_hessian.py:88-91) -- on G10's geometries with a small non-zero gradient (it scales the eigenvalues), through the class, through
+    the dispatcher by name and through the fall-back, and the dispatcher's `clip` modifier (approx_hessian.py:104-110) on top of it."""
+    from multioptpy.ModelHessian.lindh2007d3 import Lindh2007D3ApproxHessian
+    from multioptpy.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(HERE, "g10_model_hessian.npz"))
+    out = {"tags": z["tags"]}
+    rng = np.random.default_rng(107)
+    for tag in z["tags"]:
+        x, elems = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]]
+        g = rng.normal(0.0, 0.02, x.shape)
+        with quiet():
+            H = Lindh2007D3ApproxHessian().main(x.copy(), list(elems), g.copy())
+            Hd = ApproxHessian().main(x.copy(), list(elems), g.copy(), approx_hess_type="lindh2007d3")
+            Hf = ApproxHessian().main(x.copy(), list(elems), g.copy(), approx_hess_type="no_such_model")
+            Hc = ApproxHessian().main(x.copy(), list(elems), g.copy(), approx_hess_type="lindh2007d3_clip")
+        out[tag + "_x"], out[tag + "_elems"], out[tag + "_g"] = x, z[tag + "_elems"], g
+        out[tag + "_H"], out[tag + "_Hdisp"], out[tag + "_Hfallback"], out[tag + "_Hclip"] = np.array(H), np.array(Hd), np.array(Hf), np.array(Hc)
+    np.savez_compressed(os.path.join(HERE, "g10c_lindh2007d3.npz"), **out)
+    print("G10c:", len(out["tags"]), "geometries")
 
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g11", "g12", "g13", "g14"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -940,6 +961,8 @@ if __name__ == "__main__":
         g14_keep_pot()
     if "g10b" in which:
         g10b_model_hessian_variants()
+    if "g10c" in which:
+        g10c_lindh2007d3()
     if "g11" in which:
         g11_afir()
     if "g12" in which:

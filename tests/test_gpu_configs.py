@@ -357,7 +357,7 @@ def test_model_hessian_fischerd3old_vs_reference():
     Hb = ApproxHessian().batch(np.array([z[a + "_x"], z[b + "_x"]]), el)
     assert np.abs(Hb[0] - z[a + "_H"]).max() < 1e-8 and np.abs(Hb[1] - z[b + "_H"]).max() < 1e-8
     with pytest.raises(NotImplementedError):
-        ApproxHessian().main(z[a + "_x"], el, None, approx_hess_type="lindh2007d3")
+        ApproxHessian().main(z[a + "_x"], el, None, approx_hess_type="swartd3")          # (a model the device does not have)
     print("model Hessian: worst deviation from the reference", worst)
 
 
@@ -397,6 +397,30 @@ def test_model_hessian_fischer_variants_vs_reference():
         assert np.abs(band.get_hessian(i) - ref).max() < 1e-9
     band.close()
     print("model Hessian variants: worst deviation from the reference", worst)
+
+
+def test_model_hessian_lindh2007d3_vs_reference():
+    """G10c: Lindh2007D3 on the device (kind MOPT_MODEL_LINDH2007D3: pair / triple / quadruple terms assembled per atom-pair block, the
+    reference's mirroring rule, projection, eigen-decomposition, |lambda| 0.1 exp(-|g|^2)) against the reference's outputs on its five
+    organic test geometries, argon clusters, a distorted copy and linear CO2 -- through the class's dispatcher by name, through the
+    fall-back for an unknown name, with the `clip` modifier, and as a batch."""
+    import os
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g10c_lindh2007d3.npz"))
+    worst = 0.0
+    for tag in z["tags"]:
+        x, el, g = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]], z[tag + "_g"]
+        H = ApproxHessian().main(x, el, g, approx_hess_type="lindh2007d3")
+        d = np.abs(H - z[tag + "_H"]).max()
+        worst = max(worst, d)
+        assert d < 1e-10, (tag, d)
+        assert np.abs(ApproxHessian().main(x, el, g, approx_hess_type="not_a_model") - z[tag + "_Hfallback"]).max() < 1e-10, tag
+        assert np.abs(ApproxHessian().main(x, el, g, approx_hess_type="lindh2007d3_clip") - z[tag + "_Hclip"]).max() < 1e-10, tag
+    x, el, g = z["aldol_rxn_x"], [str(e) for e in z["aldol_rxn_elems"]], z["aldol_rxn_g"]
+    x2, g2 = z["aldol_jitter_x"], z["aldol_jitter_g"]
+    Hb = ApproxHessian().batch(np.stack([x, x2]), el, "lindh2007d3", cart_gradients=np.stack([g, g2]))
+    assert np.abs(Hb[0] - z["aldol_rxn_H"]).max() < 1e-10 and np.abs(Hb[1] - z["aldol_jitter_H"]).max() < 1e-10
+    print("Lindh2007D3 on the device vs the reference: worst deviation", worst)
 
 
 def test_model_hessian_large_cluster_vs_oracle():

@@ -346,7 +346,7 @@ def test_g10_model_hessian_oracle_vs_reference():
         assert np.abs(H - z[t + "_H"]).max() < 1e-13, t
         assert np.array_equal(z[t + "_H"], z[t + "_Hdisp"]), t
     with pytest.raises(NotImplementedError):
-        mh.approx_hessian(z["co2_x"], ["O", "C", "O"], None, "lindh2007d3")
+        mh.approx_hessian(z["co2_x"], ["O", "C", "O"], None, "swartd3")          # (not restated)
 
 
 def test_g10b_model_hessian_variants_oracle_vs_reference():
@@ -495,3 +495,22 @@ def test_g13_path_tools_oracle_and_host_glue_vs_reference():
     print("climbing-image move: oracle", np.abs(np.array(ci_o) - z["ci_out"]).max(), "package", np.abs(np.array(ci_p) - z["ci_out"]).max())
     assert np.abs(np.array(ci_o) - z["ci_out"]).max() < 1e-9
     assert np.abs(np.array(ci_p) - z["ci_out"]).max() < 1e-9
+
+
+def test_oracle_lindh2007d3_vs_reference():
+    """G10c: the oracle's Lindh2007D3 restatement (all pairs / triples / quadruples, the reference's triangle-wise accumulation and its
+    mirroring rule, projection, |lambda| scaling by the gradient norm) against Lindh2007D3ApproxHessian.main, the dispatcher by name,
+    the dispatcher's fall-back for an unknown name, and the `clip` modifier."""
+    import os
+    import numpy as np
+    from oracle import model_hessian as mh
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10c_lindh2007d3.npz"))
+    for tag in z["tags"]:
+        x, el, g = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]], z[tag + "_g"]
+        assert np.array_equal(z[tag + "_H"], z[tag + "_Hdisp"]) and np.array_equal(z[tag + "_H"], z[tag + "_Hfallback"])
+        if len(el) > 15:
+            continue                                        # (the Python quadruple loops: kept to seconds)
+        H = mh.approx_hessian(x, el, g, "lindh2007d3")
+        assert np.abs(H - z[tag + "_H"]).max() < 1e-12, tag
+        assert np.abs(mh.approx_hessian(x, el, g, "some_unknown_name") - z[tag + "_Hfallback"]).max() < 1e-12, tag
+        assert np.abs(mh.approx_hessian(x, el, g, "lindh2007d3_clip") - z[tag + "_Hclip"]).max() < 1e-12, tag
