@@ -165,6 +165,69 @@ def library_stamp():
     return h.hexdigest()[:12]
 
 
+def main_single(args):
+    """One geometry through the plugin classes: what optmain calls per iteration (optimizer.py:685-697).  A step = one `run` call incl. the
+    PCIe traffic of its host arrays (the plugin boundary hands over host ndarrays); inputs of every step come from the optimizer's own
+    trajectory on the LJ surface.  cpu_baseline: the oracle's classes (NumPy restatement) on the same inputs, one BLAS thread."""
+    import contextlib
+    import io
+    import cases
+    from threadpoolctl import threadpool_limits
+    from multioptpy_amd.Optimizer.rsirfo import RSIRFO
+    from multioptpy_amd.Optimizer.rsprfo import EnhancedRSPRFO
+    from oracle.rsirfo import RSIRFO as ORSIRFO
+    from oracle.rsprfo import EnhancedRSPRFO as ORSPRFO
+    N = args.single_geometry
+    n = 3 * N
+    W, K = max(1, args.warmup), args.steps
+    x0 = cases.cluster(N, jitter=0.3) * 0.95
+    H0 = cases.lj(x0, hessian=True)[2]
+
+    def trajectory(cls, method, order, nstep, quiet):
+        opt = cls(method=method, saddle_order=order, element_list=["Ar"] * N)
+        opt.set_hessian(H0.copy())
+        opt.set_bias_hessian(np.zeros((n, n)))
+        xs, px, pg, pe = x0.copy(), [], [], 0.0
+        times = []
+        for _ in range(nstep):
+            e, g = cases.lj(xs)[:2]
+            t0 = time.perf_counter()
+            if quiet:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    mv = opt.run(xs.reshape(-1, 1), g.reshape(-1, 1), pg, px, e, pe, [], [], g.reshape(-1, 1), pg)
+            else:
+                mv = opt.run(xs.reshape(-1, 1), g.reshape(-1, 1), pg, px, e, pe, [], [], g.reshape(-1, 1), pg)
+            times.append(time.perf_counter() - t0)
+            px, pg, pe = xs.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), e
+            step = np.asarray(mv).reshape(N, 3)
+            xs = xs - step * min(1.0, 0.1 / max(np.linalg.norm(step), 1e-12))
+        return times, xs
+
+    out = {}
+    for name, cls, ocls, method, order in (("RSIRFO.run", RSIRFO, ORSIRFO, "rsirfo_bfgs", 0), ("EnhancedRSPRFO.run", EnhancedRSPRFO, ORSPRFO, "rsprfo_bofill", 1)):
+        tg, xg = trajectory(cls, method, order, W + K, False)
+        with threadpool_limits(limits=1):
+            tc, xc = trajectory(ocls, method, order, W + K, True)
+        out[name] = {"gpu_ms": 1e3 * float(np.median(tg[W:])), "gpu_min_ms": 1e3 * float(np.min(tg[W:])),
+                     "cpu_ms": 1e3 * float(np.median(tc[W:])), "cpu_min_ms": 1e3 * float(np.min(tc[W:])),
+                     "max_abs_dev_final_geometry_bohr": float(np.abs(xg - xc).max())}
+    line = {
+        "metric": "optimizer-step ms (Hessian update+RFO, QM excluded), single geometry", "value": out["RSIRFO.run"]["gpu_ms"], "unit": "ms/step",
+        "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": out["RSIRFO.run"]["gpu_ms"], "higher_is_better": False, "scaling": "replicas only",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"RSIRFO.run (rsirfo_bfgs) through the plugin class, one {N}-atom Ar LJ cluster (n={n}), exact LJ Hessian at the start, "
+                               "host ndarrays in and out (PCIe included)", "atoms": N,
+                   "second": f"EnhancedRSPRFO.run (rsprfo_bofill, saddle order 1): {out['EnhancedRSPRFO.run']['gpu_ms']:.4f} ms"},
+        "roofline": None,
+        "cpu_baseline": {"value": out["RSIRFO.run"]["cpu_ms"], "unit": "ms/step", "cores": 1, "kind": "port",
+                         "sample": f"the oracle's RSIRFO.run (oracle/rsirfo.py) on the same {K} steps of its own trajectory, 1 BLAS thread, stdout suppressed; "
+                                   f"EnhancedRSPRFO.run: {out['EnhancedRSPRFO.run']['cpu_ms']:.4f} ms",
+                         "host_cpus": os.cpu_count()},
+        "classes": out,
+    }
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,7 +240,12 @@ def main():
     ap.add_argument("--no-second-workload", action="store_true", help="skip the short exact-Hessian-start measurement reported beside the line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--single-geometry", type=int, default=0, metavar="NATOMS",
+                    help="BASELINE configs 2 / 3 (optmain on one geometry): time RSIRFO.run and EnhancedRSPRFO.run through the plugin classes "
+                         "(host arrays in and out) for an N-atom LJ cluster, with the oracle classes on the host beside them")
     args = ap.parse_args()
+    if args.single_geometry > 0:
+        return main_single(args)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

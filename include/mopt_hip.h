@@ -281,6 +281,8 @@ int mopt_band_destroy(mopt_band *band);
 int mopt_band_set_shard(mopt_band *band, int first, int count);
 /* H = NULL -> identity (rfo_neb.py:25). */
 int mopt_band_set_hessian(mopt_band *band, int image, const double *H);
+/* H_image += 0.5 (B + B^T) on the device: the bias Hessian that nebmain's _apply_bias_potential adds to tmp_hessian_{i}.npy (neb.py:806-832) */
+int mopt_band_add_hessian(mopt_band *band, int image, const double *B);
 int mopt_band_get_hessian(mopt_band *band, int image, double *H);
 int mopt_band_get_state(mopt_band *band, int image, mopt_rsirfo_state *out);
 /* options: ratio_of_rfo_step (rfo_neb.py:98), fix_init_edge / fix_end_edge (trust_radius_neb.py:7-8),

@@ -33,6 +33,8 @@ class RFOOptimizer:
         self.optimizer_instance_list = []     # kept for API compatibility (state lives on the device)
         self._pending_hessians = None         # in-memory counterpart of the tmp_hessian_i.npy side channel
         self._pending_model = None
+        self._pending_bias = None             # bias Hessians of the next step (neb.py:806-832)
+        self._have_files = False              # the band holds "tmp_hessian_i.npy" contents (stepped before, or Hessians were handed over)
 
     def close(self):
         """Release the device-resident band (Hessians, optimizer state, exchange streams and communicators)."""
@@ -53,6 +55,12 @@ class RFOOptimizer:
         """Hand over one Hessian per image (or None to keep an image's current one) for the next `optimize` call: what the
         calculators do in the reference by writing tmp_hessian_{i}.npy (e.g. lj_calculation_tools.py:350-353)."""
         self._pending_hessians = list(hessians)
+
+    def set_bias_hessians(self, bias_hessians):
+        """One bias Hessian per image for the next `optimize` call: nebmain's _apply_bias_potential (neb.py:806-832) adds it to the
+        image's tmp_hessian_{i}.npy when that file exists (every step: it accumulates, as in the reference) and, when no file exists yet,
+        writes a non-zero bias Hessian AS the file -- the optimizer then starts that image from the bias Hessian alone."""
+        self._pending_bias = [None if b is None else np.asarray(b, dtype=np.float64) for b in bias_hessians]
 
     def request_model_hessian(self, element_list, approx_hess_type="fischerd3old"):
         """The next `optimize` call first replaces every image's Hessian by the model Hessian of its geometry, computed on the
@@ -88,11 +96,26 @@ class RFOOptimizer:
             for i in range(I):
                 f = self._file(i)
                 self.band.set_hessian(i, np.load(f) if os.path.exists(f) else None)
+        fresh = optimize_num == 0                              # (the band was re-created above: identity Hessians, no "files")
+        if fresh:
+            self._have_files = False
+        have = [self._have_files or self.persist] * I
         if self._pending_hessians is not None:
             for i, h in enumerate(self._pending_hessians):
                 if h is not None:
                     self.band.set_hessian(i, np.asarray(h, dtype=np.float64))
+                    have[i] = True
             self._pending_hessians = None
+        if self._pending_bias is not None:
+            for i, b in enumerate(self._pending_bias):
+                if b is None:
+                    continue
+                if have[i]:
+                    self.band.add_hessian(i, b)
+                elif not np.allclose(b, 0):
+                    self.band.set_hessian(i, b)
+            self._pending_bias = None
+        self._have_files = True                                  # (every image's Hessian is "saved" behind the step, rfo_neb.py:175)
         self.band.upload(X, E, G)
         if self._pending_model is not None:
             self.band.model_hessian(*self._pending_model)

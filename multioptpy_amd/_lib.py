@@ -62,6 +62,7 @@ def _proto(lib):
         lib.mopt_band_set_shard.argtypes = [vp, C.c_int, C.c_int]
         lib.mopt_band_set_hessian.argtypes = [vp, C.c_int, DP]
         lib.mopt_band_get_hessian.argtypes = [vp, C.c_int, DP]
+        lib.mopt_band_add_hessian.argtypes = [vp, C.c_int, DP]
         lib.mopt_band_get_state.argtypes = [vp, C.c_int, C.POINTER(_abi.RsirfoState)]
         lib.mopt_band_configure.argtypes = [vp, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.mopt_band_upload.argtypes = [vp, DP, DP, DP]

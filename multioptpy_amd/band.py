@@ -38,6 +38,11 @@ class Band:
         Hc = None if H is None else f64(H)
         check(lib().mopt_band_set_hessian(self._h, int(image), ptr(Hc)), self._ctx)
 
+    def add_hessian(self, image, B):
+        """H_image += sym(B) on the device (a bias Hessian, neb.py:806-832)."""
+        Bc = f64(B)
+        check(lib().mopt_band_add_hessian(self._h, int(image), ptr(Bc)), self._ctx)
+
     def get_hessian(self, image):
         H = np.empty((self.n, self.n))
         check(lib().mopt_band_get_hessian(self._h, int(image), ptr(H)), self._ctx)

@@ -371,6 +371,33 @@ extern "C" int mopt_band_set_hessian(mopt_band *b, int image, const double *H) {
     return MOPT_OK;
 }
 
+namespace mopt { __global__ void __launch_bounds__(256) k_band_add_sym(int n, const double *__restrict__ B, double *__restrict__ H) {
+    // H += 0.5 (B + B^T), element (i, j) and (j, i) through the same operations: a bitwise symmetric H stays bitwise symmetric
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)n * n) return;
+    const int i = (int)(e / n), j = (int)(e - (size_t)i * n);
+    const double a = B[(size_t)i * n + j], c = B[(size_t)j * n + i];
+    H[e] += (i <= j) ? 0.5 * (a + c) : 0.5 * (c + a);
+} }
+
+// H_image += B (symmetrised): the bias Hessian of nebmain's _apply_bias_potential (neb.py:806-832 adds it to tmp_hessian_i.npy every step)
+extern "C" int mopt_band_add_hessian(mopt_band *b, int image, const double *B) {
+    if (!b || !B) return MOPT_E_ARG;
+    hipSetDevice(b->ctx->device);
+    BTRY(mopt_band_alloc_internal(b));
+    const int loc = band_local(b, image);
+    if (loc < 0) return MOPT_E_ARG;
+    mopt_ctx *ctx = b->ctx;
+    const size_t nn = (size_t)b->n * b->n;
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(b->wk.Gt, B, nn * 8, hipMemcpyHostToDevice, ctx->stream));      // (Gt: scratch of the eigen-solver, free between steps)
+    hipLaunchKernelGGL(mopt::k_band_add_sym, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, b->n, (const double *)b->wk.Gt, b->wk.H + loc * nn);
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    b->dense_hessians = true;
+    b->have_vecs = false;
+    return MOPT_OK;
+}
+
 extern "C" int mopt_band_get_hessian(mopt_band *b, int image, double *H) {
     if (!b || !H) return MOPT_E_ARG;
     hipSetDevice(b->ctx->device);

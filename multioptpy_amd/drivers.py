@@ -59,8 +59,13 @@ class ConvergenceChecker:
 
 def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, saddle_order=0, NSTEP=300, FC_COUNT=-1,
                   max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False, model_hessian=None,
-                  MFC_COUNT=50, afir=None, keep_pot=None):
-    """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy)."""
+                  MFC_COUNT=50, afir=None, keep_pot=None, projection_constraint=None):
+    """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy).
+    projection_constraint: `-pc` as dict(conditions=[...], atoms=[[...], ...], constants=[...]) (interface.py:453-475): a ProjectOutConstrain
+    object goes to CalculateMoveVector, whose crsirfo_* keys then build the constrained optimizer (optimizer.py:450-451, optimization.py:1810-1829).
+    The driver's OWN projection steps (gradient / Hessian projection, SHAKE-like adjustment of the new geometry; optimization.py:1182-1198,
+    1345-1368) run only when an -opt entry is literally "crsirfo" (optimization.py:1163) -- a name that matches no optimizer key, so the
+    reference then steps with FIRE; that combination is outside this package and raises."""
     natom = len(element_list)
     geometry = np.array(start_geometry_ang, dtype="float64") / BOHR2ANGSTROMS
     initial_geometry = copy.deepcopy(geometry)
@@ -70,13 +75,20 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
     pre_move_vector = np.zeros((natom, 3))
     pre_bias_energy = 0.0
     Model_hess = np.eye(natom * 3)
-    CMV = CalculateMoveVector("x", element_list, saddle_order, FC_COUNT, 0.0, None, max_trust_radius=max_trust_radius,
-                              min_trust_radius=min_trust_radius)
     methods = opt_method if isinstance(opt_method, (list, tuple)) else [opt_method]
+    PC = None
+    if projection_constraint:
+        from .Constraint.constraint_condition import ProjectOutConstrain
+        PC = ProjectOutConstrain(projection_constraint["conditions"], projection_constraint["atoms"], projection_constraint.get("constants", []))
+        if any(str(m).lower() == "crsirfo" for m in methods):
+            raise NotImplementedError("-opt crsirfo (the literal name) selects the reference's FIRE optimizer with driver-side projections: not part of this package")
+    CMV = CalculateMoveVector("x", element_list, saddle_order, FC_COUNT, 0.0, None, max_trust_radius=max_trust_radius,
+                              min_trust_radius=min_trust_radius, projection_constraint=PC)
     optimizer_instances = CMV.initialization(list(methods))
     for opt in optimizer_instances:
         opt.set_hessian(Model_hess)
-    convergence = ConvergenceChecker()
+    # (`-pc` quadruples the displacement thresholds: optimization.py:133-135)
+    convergence = ConvergenceChecker(max_displacement=6e-3, rms_displacement=4e-3) if projection_constraint else ConvergenceChecker()
     tools = Calculationtools()
     converged = False
     energy = None
@@ -169,7 +181,7 @@ def make_band(frames_ang, partition):
 
 def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
                   ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999, devices=None,
-                  transport="rccl", model_hessian=None, MFC_COUNT=50, align_distances=0, climbing_image=(999999, 999999)):
+                  transport="rccl", model_hessian=None, MFC_COUNT=50, align_distances=0, climbing_image=(999999, 999999), afir=None, keep_pot=None):
     """Band relaxation as in nebmain: with FC_COUNT != -1 the Hessian-based branch (`-fc`: RFOOptimizer on a BNEB force),
     otherwise the default FIRE optimizer, replaced by steepest descent from iteration `steepest_descent` on (`-sd`,
     neb.py:794-804, 939-948).
@@ -178,7 +190,9 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
     (neb.py:497-597): energies/gradients -> BNEB force -> RFOOptimizer.optimize (which recomputes the force, rfo_neb.py:131)
     -> climbing-image move when due (`-ci start interval`, neb.py:561-564) -> edge fixing -> sequential Kabsch k -> k+1 (centres image
     k+1 in place) -> equal-arc-length re-distribution every `align_distances` iterations (`-ad`, neb.py:649-766; the other
-    `-ad*` strategies are not built) -> `%17.12f` quantisation."""
+    `-ad*` strategies are not built) -> `%17.12f` quantisation.
+    afir / keep_pot (as for optmain_steps): the bias of NEB._apply_bias_potential (neb.py:806-832) per image -- energy and gradient added to the
+    engine's, the bias Hessian added to the image's resident Hessian every step (or taken AS the Hessian while the image has none)."""
     from .MEP.pathopt_bneb_force import CaluculationBNEB
     from .Optimizer.rfo_neb import RFOOptimizer
     from .Optimizer.fire_neb import FIREOptimizer
@@ -216,6 +230,25 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
         X = np.asarray(X, dtype="float64")
         if hessians is not None and rfo_branch:
             optimizer.set_image_hessians(hessians)
+        E_raw = E.copy()
+        if afir is not None or keep_pot:
+            Bh = []
+            for i in range(len(X)):
+                be, bg, bh = 0.0, np.zeros_like(X[i]), np.zeros((3 * X.shape[1], 3 * X.shape[1]))
+                if afir is not None:
+                    from .Potential.AFIR_potential import AFIRPotential
+                    pot = AFIRPotential(AFIR_gamma=afir["gamma"], AFIR_Fragm_1=afir["fragm_1"], AFIR_Fragm_2=afir["fragm_2"], element_list=element_list)
+                    e1, g1, h1 = pot.calc_energy_gradient_hessian(X[i], [afir["gamma"]])
+                    be, bg, bh = be + e1, bg + g1, bh + h1
+                if keep_pot:
+                    from .Potential.keep_potential import keep_pot_sum
+                    e1, g1, h1 = keep_pot_sum(X[i], [p["pair"] for p in keep_pot], [p["k"] for p in keep_pot], [p["r0"] for p in keep_pot])
+                    be, bg, bh = be + e1, bg + g1, bh + h1
+                E[i] += be
+                G[i] += bg
+                Bh.append(bh)
+            if rfo_branch and (FC_COUNT > 0 or (MFC_COUNT > 0 and bool(model_hessian))):      # neb.py:819
+                optimizer.set_bias_hessians(Bh)
         if FC_COUNT == -1 and model_hessian and optimize_num % MFC_COUNT == 0:          # neb.py:515-523
             optimizer.request_model_hessian(element_list, model_hessian)
         if optimize_num == 0:
@@ -245,7 +278,7 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
         if optimize_num > 0 and align_distances >= 1 and optimize_num % align_distances == 0:      # NEB._align_geometries
             new_geometry = np.array(distribute_geometry(np.array(new_geometry)), dtype="float64")
         if record is not None:
-            record.append(dict(E=E.copy(), G=G.copy(), X=X.copy(), opt=opt_out, post=new_geometry.copy(),
+            record.append(dict(E=E_raw, G=G.copy(), X=X.copy(), opt=opt_out, post=new_geometry.copy(),
                                hess=[optimizer.get_image_hessian(i) for i in range(len(X))] if rfo_branch else [],
                                fire=None if rfo_branch else (optimizer.dt, optimizer.a, optimizer.n_reset)))
         pre_geom, pre_gradients, pre_total_velocity = copy.copy(X), copy.copy(G), copy.copy(total_velocity)

@@ -1,5 +1,5 @@
 """Drop-in for multioptpy/optimizer.py::CalculateMoveVector restricted to the quasi-Newton methods of the hot path
-(rsirfo_* -> RSIRFO, rsprfo_* -> EnhancedRSPRFO).
+(rsirfo_* -> RSIRFO, rsprfo_* -> EnhancedRSPRFO, crsirfo_* with a projection constraint -> CRSIRFO).
 
 Same constructor, `initialization(method)` and `calc_move_vector(...)` signatures and return values as the reference
 (optimizer.py:259-307, 309-533, 740-818).  The step itself comes from the device-backed optimizer classes; the outer
@@ -14,13 +14,14 @@ import numpy as np
 from . import ops
 from .Optimizer.rsirfo import RSIRFO
 from .Optimizer.rsprfo import EnhancedRSPRFO
+from .Optimizer.crsirfo import CRSIRFO
 from .Optimizer.trust_radius import TrustRadius
 
 BOHR2ANGSTROMS = 0.52917721067          # Parameters/parameter.py:27
 
 _ENHANCEMENTS = ("lookahead", "lars", "linesearch", "gdiis", "kdiis", "adiis", "c2diis", "ediis", "coordinate_locking",
                  "component_wise_scaling", "gpr_step", "gan_step", "rl_step", "geodesic_step", "trim")
-_OTHER_NEWTON = ("mf_rsirfo", "crsirfo")
+_OTHER_NEWTON = ("mf_rsirfo",)
 
 
 class CalculateMoveVector:
@@ -72,6 +73,11 @@ class CalculateMoveVector:
             if "rsprfo" in low:
                 opt = EnhancedRSPRFO(method=m, saddle_order=self.saddle_order, element_list=self.element_list,
                                      trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius)
+            elif "crsirfo" in low and self.projection_constraint:
+                # optimizer.py:450-451: the constrained (null-space) RS-I-RFO when a ProjectOutConstrain object came with the constructor
+                # (`-pc`); without one the key falls through to the plain RSIRFO below, as in the reference
+                opt = CRSIRFO(method=m, constraints=self.projection_constraint, saddle_order=self.saddle_order, element_list=self.element_list,
+                              trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius)
             elif "rsirfo" in low:
                 opt = RSIRFO(method=m, saddle_order=self.saddle_order, element_list=self.element_list,
                              trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius)

@@ -207,6 +207,9 @@ class ShardedBand:
     def set_hessian(self, image, H):
         self._owner(image).set_hessian(image, H)
 
+    def add_hessian(self, image, B):
+        self._owner(image).add_hessian(image, B)
+
     def get_hessian(self, image):
         return self._owner(image).get_hessian(image)
 

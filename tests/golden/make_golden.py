@@ -767,6 +767,8 @@ def g8_optmain():
     _run_optmain("a", 7, ["-opt", "rsirfo_bfgs", "-ns", "8"], out)
     _run_optmain("b", 13, ["-opt", "rsirfo_block_fsb", "-ns", "8", "-fc", "5"], out)
     _run_optmain("c", 7, ["-opt", "rsprfo_bofill", "-order", "1", "-ns", "6", "-fc", "5"], out)
+    # `-pc`: a bond and an angle kept by the constrained optimizer the dispatcher builds for crsirfo_* keys (optimizer.py:450-451)
+    _run_optmain("d", 7, ["-opt", "crsirfo_bfgs", "-ns", "6", "-pc", "bond", "1,2", "angle", "3,4,5"], out)
     np.savez_compressed(os.path.join(HERE, "g8_optmain.npz"), **out)
 
 
@@ -917,6 +919,7 @@ def g8_nebmain():
     _run_nebmain("a", 7, ["-fc", "3", "-ns", "5", "-p", "5", "-ad", "2"], out)         # images re-distributed on iterations 2 and 4
     _run_nebmain("c", 7, ["-fc", "3", "-ns", "5", "-p", "5", "-ci", "1", "2"], out)    # climbing-image move on iteration 3
     _run_nebmain("n", 7, ["-fc", "3", "-ns", "5", "-p", "5"], out)
+    _run_nebmain("m", 7, ["-fc", "2", "-ns", "4", "-p", "5", "-ma", "150", "1,2", "5,6"], out)      # AFIR bias per image (neb.py:806-832)
     _run_nebmain("e", 7, ["-fc", "2", "-ns", "4", "-p", "5", "-fe", "3"], out)
     _run_nebmain("f", 7, ["-ns", "9", "-p", "5"], out)                       # FIRE branch (the default optimizer of nebmain)
     _run_nebmain("s", 7, ["-ns", "6", "-p", "5", "-sd", "3", "-fe", "1"], out)     # FIRE, then steepest descent from iteration 3

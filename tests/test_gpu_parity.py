@@ -490,7 +490,7 @@ def test_outer_trust_radius_vs_reference():
             assert abs(tr - z[f"c{c}_tr"][k]) < 1e-12, (c, k)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_optmain_driver_vs_reference(tag):
     """a15/a20/a23: the in-memory optmain iteration on the device path against the reference driver's own trajectory (G8):
     geometry, move vector, new geometry, Hessian, outer trust radius, displacement and convergence thresholds per iteration."""
@@ -500,9 +500,9 @@ def test_optmain_driver_vs_reference(tag):
     from test_oracle_golden import _check_optmain
     z = np.load(os.path.join(G, "g8_optmain.npz"))
 
-    def run(x0, elems, method, order, nstep, fc, rec):
+    def run(x0, elems, method, order, nstep, fc, rec, pc=None):
         calc = cases.LJCalculator(FC_COUNT=fc, project=pj.project_hessian_trrot)      # the Calculator is upstream of the path
-        drivers.optmain_steps(calc, x0, elems, method, order, nstep, fc, record=rec)
+        drivers.optmain_steps(calc, x0, elems, method, order, nstep, fc, record=rec, projection_constraint=pc)      # (d: `-pc`, CRSIRFO via the dispatcher)
 
     worst = _check_optmain(run, z, tag, 1e-8)
     print("optmain", tag, "worst move-vector deviation from the reference", worst)
@@ -547,7 +547,7 @@ def test_optmain_driver_with_bias_vs_oracle(kind):
     print("biased optmain", kind, "worst deviation from the oracle's driver", worst)
 
 
-@pytest.mark.parametrize("tag", ["n", "e", "f", "s", "a", "c"])
+@pytest.mark.parametrize("tag", ["n", "e", "f", "s", "a", "c", "m"])
 def test_nebmain_driver_vs_reference(tag):
     """a23: the in-memory nebmain iteration (RFO branch) on the device path against the reference driver's own band
     trajectory (G8): geometry read by the engine, optimizer output, geometry after edge fixing + Kabsch chain, Hessians."""

@@ -254,7 +254,14 @@ def _check_optmain(run, z, tag, tol):
     # the start file holds 10 decimals
     x0 = np.array([[float(f"{v:.10f}") for v in r] for r in x0])
     rec = []
-    run(x0, ["Ar"] * len(x0), method, order, nstep, fc, rec)
+    if "-pc" in argv:                                          # `-pc name atoms name atoms ...` (interface.py:466-475)
+        i = argv.index("-pc") + 1
+        conds, atoms = [], []
+        while i + 1 < len(argv) and not argv[i].startswith("-"):
+            conds.append(argv[i]); atoms.append([int(a) for a in argv[i + 1].split(",")]); i += 2
+        run(x0, ["Ar"] * len(x0), method, order, nstep, fc, rec, dict(conditions=conds, atoms=atoms))
+    else:
+        run(x0, ["Ar"] * len(x0), method, order, nstep, fc, rec)
     assert len(rec) == int(z[tag + "_nit"])
     worst = 0.0
     for k, r in enumerate(rec):
@@ -272,16 +279,17 @@ def _check_optmain(run, z, tag, tol):
     return worst
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
 def test_g8_optmain_driver(tag):
-    """a15/a20/a23: the oracle's in-memory optmain iteration against the reference driver's own trajectory."""
+    """a15/a20/a23: the oracle's in-memory optmain iteration against the reference driver's own trajectory (d: `-opt crsirfo_bfgs -pc bond
+    1,2 angle 3,4,5` -- the constrained optimizer through the dispatcher)."""
     import cases
     from oracle import driver, projection as pj
     z = np.load(os.path.join(G, "g8_optmain.npz"))
 
-    def run(x0, elems, method, order, nstep, fc, rec):
+    def run(x0, elems, method, order, nstep, fc, rec, pc=None):
         calc = cases.LJCalculator(FC_COUNT=fc, project=pj.project_hessian_trrot)
-        driver.run_optmain(calc, x0, elems, method, order, nstep, fc, record=rec)
+        driver.run_optmain(calc, x0, elems, method, order, nstep, fc, record=rec, projection_constraint=pc)
 
     worst = _check_optmain(run, z, tag, 1e-9)
     print("optmain", tag, "worst move-vector deviation", worst)
@@ -302,6 +310,9 @@ def _check_nebmain(run, z, tag, tol):
         extra["align_distances"] = int(argv[argv.index("-ad") + 1])
     if "-ci" in argv:
         extra["climbing_image"] = (int(argv[argv.index("-ci") + 1]), int(argv[argv.index("-ci") + 2]))
+    if "-ma" in argv:                                          # `-ma gamma fragm_1 fragm_2` (AFIR, kJ/mol; 1-based atoms)
+        i = argv.index("-ma")
+        extra["afir"] = dict(gamma=float(argv[i + 1]), fragm_1=[int(a) for a in argv[i + 2].split(",")], fragm_2=[int(a) for a in argv[i + 3].split(",")])
     run(ends, fc, nstep, p, fe, rec, sd, **extra)
     assert len(rec) == int(z[tag + "_nit"])
     worst = 0.0
@@ -321,15 +332,20 @@ def _check_nebmain(run, z, tag, tol):
     return worst
 
 
-@pytest.mark.parametrize("tag", ["n", "e", "f", "s", "a", "c"])
+@pytest.mark.parametrize("tag", ["n", "e", "f", "s", "a", "c", "m"])
 def test_g8_nebmain_driver(tag):
     """a23: the oracle's in-memory nebmain iteration (RFO branch; FIRE branch; FIRE then steepest descent; RFO branch with image
     re-distribution `-ad 2` and with the climbing-image move `-ci 1 2`) against the reference driver's own band trajectory."""
     from oracle import driver
 
-    def run(ends, fc, nstep, p, fe, rec, sd, **extra):
+    def run(ends, fc, nstep, p, fe, rec, sd, afir=None, **extra):
         eng = cases.LJEngine(FC_COUNT=fc, project=pj.project_hessian_trrot)
-        driver.run_nebmain(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, literal=True, sd_from=sd, **extra)
+        bias = None
+        if afir is not None:                                   # (m: `-ma`, the per-image bias of neb.py:806-832 with the oracle's analytic AFIR, pinned by G11)
+            from oracle import afir as oafir, model_hessian as mh
+            cov = mh.element_params(["Ar"] * ends.shape[1])["cov"]
+            bias = lambda x: oafir.afir(x, cov, afir["fragm_1"], afir["fragm_2"], afir["gamma"])
+        driver.run_nebmain(eng, ends, ["Ar"] * ends.shape[1], nstep, p, fc, fe, record=rec, literal=True, sd_from=sd, bias=bias, **extra)
 
     worst = _check_nebmain(run, np.load(os.path.join(G, "g8_nebmain.npz")), tag, 1e-9)
     print("nebmain", tag, "worst optimizer-output deviation", worst)
