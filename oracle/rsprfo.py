@@ -210,6 +210,7 @@ class EnhancedRSPRFO:
             mx = order[:self.saddle_order].tolist()
         else:
             ov = np.abs(v.T @ self.ts_mode_eigvec)
+            self.trace["basis_dependent"] = self._basis_dependent(w, ov)
             best = int(np.argmax(ov))
             if ov[best] > self.overlap_threshold:
                 self.ts_mode_idx = best
@@ -233,6 +234,31 @@ class EnhancedRSPRFO:
                 mx = order[:self.saddle_order].tolist()
         mx = [int(i) for i in mx]
         return mx, [i for i in range(n) if i not in mx]
+
+    def _basis_dependent(self, w, ov):
+        """Test infrastructure, not in the reference: does the mode choice below hang on the basis LAPACK happened to return inside a
+        group of EQUAL shifted eigenvalues?  `_shift` sets every eigenvalue below 1e-6 past the first `saddle_order` ones to
+        min_positive_eigval (rsprfo.py:341-347): the six TR modes and every surplus negative mode become exactly degenerate, the second
+        eigh (rsprfo.py:797-798) returns an arbitrary basis of that subspace, and the overlaps of its members with the tracked vector
+        (rsprfo.py:1003) are decided by rounding noise.  The choice is basis-independent when no member of such a group can
+        beat the best overlap outside the groups (if that one passes overlap_threshold) or pass the mixing threshold (if not)."""
+        srt = np.argsort(w)
+        ws, os_ = w[srt], ov[srt]
+        grp = np.zeros(len(w), dtype=bool)
+        worst = 0.0
+        i = 0
+        while i < len(ws):
+            j = i
+            while j + 1 < len(ws) and abs(ws[j + 1] - ws[i]) <= 1e-10 * max(1.0, abs(ws[i])):
+                j += 1
+            if j > i:
+                grp[i:j + 1] = True
+                worst = max(worst, float(np.sqrt(np.sum(os_[i:j + 1] ** 2))))
+            i = j + 1
+        outside = float(os_[~grp].max()) if (~grp).any() else 0.0
+        # outside > overlap_threshold: that mode wins unless a group member can exceed it; otherwise a member matters as soon as it can
+        # pass the mixing threshold
+        return bool(worst > (outside if outside > self.overlap_threshold else self.mixing_threshold))
 
     @staticmethod
     def _solve_rfo(lam, gc, alpha, mode):

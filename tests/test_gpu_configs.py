@@ -120,6 +120,12 @@ def test_band_headline_exact_hessians_vs_oracle():
     print("32 x 100 band from exact Hessians: worst deviation", worst)
 
 
+def test_band_64x200_exact_hessians_vs_oracle():
+    """BASELINE config 5 from exact LJ Hessians (64 dense 600 x 600 spectra per step): two steps against the oracle."""
+    worst, _ = _run_band(64, 200, 2, True)
+    print("64 x 200 band from exact Hessians: worst deviation", worst)
+
+
 def _check_eigh(ops, A, tol_w=1e-13, tol_o=1e-11, tol_r=5e-12):
     w, v = ops.eigh(A)
     if A.ndim == 2:

@@ -339,6 +339,48 @@ def test_rsprfo_traces_vs_reference():
     print("RSPRFO worst step deviation from the reference:", worst)
 
 
+@pytest.mark.parametrize("natoms", [7, 11, 22])
+def test_rsprfo_surplus_negative_modes_vs_oracle(natoms):
+    """A start geometry whose exact Hessian has SEVERAL negative eigenvalues (saddle order 1): the surplus ones are shifted to
+    min_positive_eigval together with the six TR modes, and the reference's second eigh returns an arbitrary basis of that
+    degenerate group.  Same inputs for both classes at every step; the move vectors must agree until the oracle reports that its
+    mode choice hangs on that basis (oracle/rsprfo.py _basis_dependent), and at least two shifted steps must come before that."""
+    import contextlib
+    import io
+    from multioptpy_amd.Optimizer.rsprfo import EnhancedRSPRFO
+    from oracle.rsprfo import EnhancedRSPRFO as Oracle
+    n = 3 * natoms
+    x0 = cases.cluster(natoms, jitter=0.3) * 0.95
+    H0 = cases.lj(x0, hessian=True)[2]
+    assert (np.linalg.eigvalsh(H0) < -1e-6).sum() >= 2
+    a = EnhancedRSPRFO(method="rsprfo_bofill", saddle_order=1, element_list=["Ar"] * natoms)
+    b = Oracle(method="rsprfo_bofill", saddle_order=1, element_list=["Ar"] * natoms)
+    for o in (a, b):
+        o.set_hessian(H0.copy())
+        o.set_bias_hessian(np.zeros((n, n)))
+    xs, px, pg, pe = x0.copy(), [], [], 0.0
+    compared, worst = 0, 0.0
+    for it in range(12):
+        e, g = cases.lj(xs)[:2]
+        ma = a.run(xs.reshape(-1, 1), g.reshape(-1, 1), pg, px, e, pe, [], [], g.reshape(-1, 1), pg)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mb = b.run(xs.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), pg, px, e, pe, [], [], g.reshape(-1, 1).copy(), pg)
+        if b.trace.get("basis_dependent", False):
+            break
+        assert a.last_info["shifted"] == int(bool(b.trace["shifted"]))
+        err = np.abs(np.asarray(ma) - np.asarray(mb)).max()
+        worst = max(worst, err)
+        assert err < 1e-9, (it, err)
+        assert abs(a.trust_radius - b.trust_radius) < 1e-12 and int(a.ts_mode_idx) == int(b.ts_mode_idx), it
+        assert np.abs(np.asarray(a.hessian) - np.asarray(b.hessian)).max() < 1e-10
+        compared += 1
+        px, pg, pe = xs.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), e
+        step = np.asarray(ma).reshape(natoms, 3)
+        xs = xs - step * min(1.0, 0.1 / max(np.linalg.norm(step), 1e-12))
+    print(f"N = {natoms}: {compared} steps compared, worst deviation {worst:.2e}")
+    assert compared >= 2
+
+
 @pytest.mark.parametrize("algo", ["tridiag", "jacobi", "tridiag-stepwise", "tridiag-persistent", "tridiag-nosmall", "tridiag-persist2",
                                   "tridiag-valubacktrans", "tridiag-group8", "tridiag-small32", "tridiag-notail", "tridiag-tail192",
                                   "tridiag-tail100w16", "tridiag-jacobismall", "tridiag-dcmin64"])
