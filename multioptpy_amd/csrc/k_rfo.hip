@@ -6,6 +6,7 @@
 // Reference: multioptpy/Optimizer/rsirfo.py:285-490, 492-657, 924-1313.
 #include "common.hpp"
 #include "logic.h"
+#include "rfo_scalar_body.hpp"
 
 namespace mopt {
 
@@ -28,31 +29,7 @@ __global__ void __launch_bounds__(256) k_vtg(int n, const double *__restrict__ V
     if (lane == 0) gt_all[(size_t)b * n + i] = d;
 }
 
-// WaveRed with a wave-level sync(): for the section of k_rfo_scalar in which the three waves of the workgroup run different solves
-// (a workgroup barrier there would have to be reached equally often by all three)
-struct WaveRedLocal : WaveRed {
-    __device__ void sync() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
-};
-
-// rsirfo.py:492-551 on an ascending array (wave-parallel)
-__device__ inline bool ill_conditioned(const WaveRed &red, const double *w, int n, double thresh) {
-    if (n < 2) return false;
-    int cnt = (int)red.sum(n, [=](int i) { return fabs(w[i]) > 1e-10 ? 1.0 : 0.0; });
-    if (cnt < 2) return true;
-    double mx = 0.0, mn = INFINITY;
-    for (int i = threadIdx.x & 63; i < n; i += WAVE) {
-        double a = fabs(w[i]);
-        if (a > 1e-10) { mx = fmax(mx, a); mn = fmin(mn, a); }
-    }
-    mx = wave_max(mx);
-    mn = -wave_max(-mn);
-    if (mn < 1e-15) return true;
-    return (mx / mn) > thresh;
-}
-
-// Three waves per image: all of them run the (cheap, identical) set-up; then wave 0 solves the RFO equations for alpha0 while waves 1 and 2
-// solve them for the two bracket values of alpha (1e-6, alpha_max) -- three of the five secular solves of a step side by side --
-// and wave 0 finishes alone (logic.h rs_step_rest).  dynamic LDS: 15 * n doubles + 3 * n ints
+// Three waves per image (rfo_scalar_body.hpp).  dynamic LDS: 15 * n doubles + 3 * n ints
 __global__ void __launch_bounds__(192) k_rfo_scalar(int n, const mopt_rsirfo_params *__restrict__ params,
                                                    mopt_rsirfo_state *__restrict__ states, const double *__restrict__ W,
                                                    const int *__restrict__ perm, const int *__restrict__ einfo,
@@ -60,223 +37,7 @@ __global__ void __launch_bounds__(192) k_rfo_scalar(int n, const mopt_rsirfo_par
                                                    const double *__restrict__ Be, const UpdateCoef *__restrict__ coef,
                                                    double *__restrict__ coef_out_, int dbg) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    // one latency-bound wave per image, usually running next to the back-transformation (pipeline.hip): highest issue priority on its SIMD
-    __builtin_amdgcn_s_setprio(3);
-    const int b = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    __shared__ double s_n2[2];
-    double *w0 = sm;             // [n] eigenvalues of the projected Hessian (ascending)
-    double *g0 = w0 + n;         // [n] v_i . g in that order
-    double *ws = g0 + n;         // [n] image-function eigenvalues, ascending, filtered (first m entries)
-    double *gs = ws + n;         // [n] matching gradient components
-    double *stp = gs + n;        // [n] step in the filtered eigenbasis
-    double *best = stp + n;      // [n] scratch
-    double *fac = best + n;      // [n] sign factor of the image function per sorted position (1, -1 or 0)
-    double *cg2 = fac + n;       // [n] (g'/alpha)^2 of the current secular solve
-    double *cw = cg2 + n;        // [n] lambda'/alpha of the current secular solve
-    double *ex = cw + n;         // [2][3][n] cg2, cw, step of the bracket solves (waves 1, 2)
-    int *vidx = (int *)(ex + 6 * n);     // [n] eigenvector (Vt row) of sorted position k
-    int *kidx = vidx + n;                // [n] sorted position k of kept entry
-    const WaveRed red;
-    const long long tp0 = dbg ? wall_clock64() : 0;
-    long long tp1 = 0, tp2 = 0, tp3 = 0;
-    const mopt_rsirfo_params p = params[b];
-    mopt_rsirfo_state st = states[b];
-    const bool bad_eig = (einfo[2 * b + 1] & 1) != 0;
-    const double *gt_all = gt_all_ + (size_t)b * n;
-    double *coef_out = coef_out_ + (size_t)b * n;
-    if (einfo[2 * b + 1] & 8) {
-        // hand-off time-out of the persistent tridiagonalisation (GPU shared with a long-running kernel): not a numerical event.  The
-        // optimizer state of this image stays as it was, so the host can solve the image again (mopt_rsirfo_retry_timeouts) and run this
-        // stage for it a second time; the step is zero until then.  jacobi_sweeps = -2 tells the two kinds of failure apart.
-        if (wid == 0) {
-            for (int k = lane; k < n; k += WAVE) coef_out[k] = 0.0;
-            if (lane == 0) states[b].jacobi_sweeps = -2;
-        }
-        return;
-    }
-
-    for (int k = lane; k < n; k += WAVE) {
-        if (bad_eig) { w0[k] = 1.0; vidx[k] = k; }
-        else { w0[k] = W[(size_t)b * n + k]; vidx[k] = perm[(size_t)b * n + k]; }
-        g0[k] = gt_all[vidx[k]];
-        fac[k] = 1.0;
-    }
-    __syncthreads();
-    // --- level shift bookkeeping (rsirfo.py:553-657).  The reference re-runs eigh on H + shift*I and subtracts the
-    // shift again; a Jacobi solve is invariant under a uniform diagonal shift (the rotation angles depend on
-    // a_pp - a_qq and a_pq only), so only the decision flag is reproduced here.
-    bool shifted = false;
-    if (p.use_level_shift) shifted = true;
-    else if (p.auto_level_shift) shifted = ill_conditioned(red, w0, n, p.condition_number_threshold);
-    // --- gradient norm of the UNPROJECTED biased gradient (rsirfo.py:312)
-    const double gnorm = sqrt(red.sum(n, [=](int i) { double v = Bg[(size_t)b * n + i]; return v * v; }));
-    if (gnorm < p.gradient_norm_threshold) st.converged = 1;
-    if (st.n_actual > 0 && fabs(st.actual[st.n_actual - 1]) < p.energy_change_threshold) st.converged = 1;
-    // --- trust radius (rsirfo.py:380-398)
-    const double energy = Be[b];
-    if (st.has_prev) {
-        const double actual = energy - st.prev_energy;
-        push3(st.actual, st.n_actual, actual);
-        if (st.n_predicted > 0) adjust_trust_radius(p, st, actual, st.predicted[st.n_predicted - 1], w0[0], gnorm);
-    }
-    // --- image function (rsirfo.py:404-427): reflect (or, in NEB mode, remove) the first saddle_order modes with |lambda| > 1e-10.
-    // P = I - c v v^T commutes with H on its eigenvectors: H* has the same eigenvectors, eigenvalue (1-c) lambda, g* = (1-c) g~.
-    {
-        int found = 0;
-        const double f = p.neb_mode ? 0.0 : -1.0;
-        for (int i = 0; i < n && found < p.saddle_order; ++i) {
-            if (fabs(w0[i]) > 1e-10) { if (lane == 0) fac[i] = f; ++found; }
-        }
-        __syncthreads();
-    }
-    // second decomposition: the level-shift decision is taken again on the image Hessian's spectrum
-    bool shifted2 = false;
-    if (p.saddle_order > 0) {
-        for (int k = lane; k < n; k += WAVE) stp[k] = fac[k] * w0[k];
-        __syncthreads();
-        if (p.use_level_shift) shifted2 = true;
-        else if (p.auto_level_shift) shifted2 = ill_conditioned(red, stp, n, p.condition_number_threshold);
-    } else {
-        shifted2 = shifted;
-    }
-    st.level_shift_applied = shifted2 ? 1 : 0;
-    if (dbg) tp1 = wall_clock64();
-    // --- ascending order of the image eigenvalues + 1e-6 filter (rsirfo.py:265-283,440)
-    // rank of entry k among the starred values (stable); saddle_order is tiny so only those entries move.
-    // The reference sorts the image eigenvalues ascending (stable) and then drops |lambda*| < 1e-6.  The starred values
-    // differ from the ascending w0 only at the <= saddle_order reflected entries ("moved"), so the sorted position of every
-    // entry follows from prefix counts: computed by the whole wave with ballots (a serial walk by one lane cost 80 us here).
-    //   unmoved u at position c among the unmoved:  rank = c + #{moved t : val_t < val_u}
-    //   moved t (t-th in index order):               rank = #{unmoved u : val_u <= val_t} + #{t' < t : val_t' <= val_t} + #{t' > t : val_t' < val_t}
-    int m = 0;
-    int *srt = kidx + n;                 // [n] index at sorted position
-    __shared__ int s_moved[8];
-    __shared__ int s_nmoved;
-    {
-        // moved entries, in index order (at most 8 are honoured, as before)
-        int off = 0;
-        for (int base = 0; base < n; base += WAVE) {
-            const int k = base + lane;
-            const bool f = (k < n) && (fac[k] != 1.0);
-            const unsigned long long mk = __ballot(f);
-            const int pos = off + __popcll(mk & ((1ull << lane) - 1ull));
-            if (f && pos < 8) s_moved[pos] = k;
-            off += __popcll(mk);
-        }
-        if (lane == 0) s_nmoved = off < 8 ? off : 8;
-        __syncthreads();
-        const int nmoved = s_nmoved;
-        // unmoved entries
-        int offu = 0;
-        for (int base = 0; base < n; base += WAVE) {
-            const int k = base + lane;
-            const bool f = (k < n) && (fac[k] == 1.0);
-            const unsigned long long mk = __ballot(f);
-            if (f) {
-                int r = offu + __popcll(mk & ((1ull << lane) - 1ull));
-                const double val = w0[k];
-                for (int t = 0; t < nmoved; ++t) { const int i = s_moved[t]; if (fac[i] * w0[i] < val) ++r; }
-                srt[r] = k;
-            }
-            offu += __popcll(mk);
-        }
-        // moved entries (entries beyond the eighth moved one keep fac != 1 but are not placed, as in the serial form)
-        for (int t = 0; t < nmoved; ++t) {
-            const int i = s_moved[t];
-            const double val = fac[i] * w0[i];
-            int cnt = 0;
-            for (int k = lane; k < n; k += WAVE) cnt += (fac[k] == 1.0 && w0[k] <= val) ? 1 : 0;
-            cnt = (int)(wave_sum((double)cnt) + 0.5);
-            for (int t2 = 0; t2 < nmoved; ++t2) {
-                if (t2 == t) continue;
-                const int i2 = s_moved[t2];
-                const double v2 = fac[i2] * w0[i2];
-                if (t2 < t ? (v2 <= val) : (v2 < val)) ++cnt;
-            }
-            if (lane == 0) srt[cnt] = i;
-        }
-        __syncthreads();
-        const int ntot = offu + nmoved;
-        // filter, keeping the order
-        int offk = 0;
-        for (int base = 0; base < ntot; base += WAVE) {
-            const int c = base + lane;
-            bool f = false;
-            int i = 0;
-            if (c < ntot) { i = srt[c]; f = !(fabs(fac[i] * w0[i]) < p.small_eigval_thresh); }
-            const unsigned long long mk = __ballot(f);
-            if (f) kidx[offk + __popcll(mk & ((1ull << lane) - 1ull))] = i;
-            offk += __popcll(mk);
-        }
-        m = offk;
-        __syncthreads();
-    }
-    for (int k = lane; k < m; k += WAVE) {
-        const int i = kidx[k];
-        ws[k] = fac[i] * w0[i];
-        gs[k] = fac[i] * g0[i];
-    }
-    __syncthreads();
-    st.prev_eigvec_size = m;
-    st.n_kept = m;
-    if (dbg) tp2 = wall_clock64();
-    // --- RS step (rsirfo.py:924-984)
-    RsResult rr;
-    rr.branch = 0; rr.alpha = p.alpha0; rr.lambda_aug0 = 0.0; rr.initial_norm = 0.0; rr.secular_iters0 = 0;
-    {
-        // (up to here all three waves have computed the same things; m, ws, gs are complete behind the barrier above)
-        const WaveRedLocal redl;
-        double lam0 = 0.0, n2_0 = 0.0;
-        int its0 = 0;
-        if (m > 0) {
-            if (wid == 0) lam0 = solve_rfo(redl, ws, gs, m, p.alpha0, stp, &n2_0, &its0, cg2, cw);
-            else {
-                double *c2 = ex + (size_t)(wid - 1) * 3 * n, *cwx = c2 + n, *stx = cwx + n, q;
-                solve_rfo(redl, ws, gs, m, wid == 1 ? 1e-6 : p.alpha_max, stx, &q, nullptr, c2, cwx);
-                if (lane == 0) s_n2[wid - 1] = q;
-            }
-        }
-        __syncthreads();
-        if (wid != 0) return;                                // (wave 0 alone from here on: the barriers below are its own)
-        if (m > 0) rr = rs_step_rest(red, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw, lam0, n2_0, its0, &s_n2[0], &s_n2[1]);
-    }
-    __syncthreads();
-    if (dbg) tp3 = wall_clock64();
-    // --- finite check (rsirfo.py:455-463) and steepest-descent fallback in the full eigenbasis
-    double nonfinite = (m > 0) ? red.sum(m, [=](int k) { return isfinite(stp[k]) ? 0.0 : 1.0; }) : 0.0;
-    for (int k = lane; k < n; k += WAVE) coef_out[k] = 0.0;
-    __syncthreads();
-    double pred = 0.0;
-    if (nonfinite > 0.0 || m == 0) {
-        // move = -gradient (projected), clipped to the trust radius; in the eigenbasis: coef_i = -g0_i * scale
-        const double gn = sqrt(red.sum(n, [=](int k) { return g0[k] * g0[k]; }));
-        double scale = 1.0;
-        if (nonfinite > 0.0 && gn > st.trust_radius) scale = st.trust_radius / gn;
-        if (m == 0 && nonfinite == 0.0) scale = 0.0;       // no usable mode: V_kept is empty, the step is the zero vector
-        for (int k = lane; k < n; k += WAVE) coef_out[vidx[k]] = -g0[k] * scale;
-        pred = red.sum(n, [=](int k) { double c = -g0[k] * scale; return g0[k] * c + 0.5 * w0[k] * c * c; });
-        if (nonfinite > 0.0) rr.branch = 3;
-    } else {
-        for (int k = lane; k < m; k += WAVE) coef_out[vidx[kidx[k]]] = stp[k];
-        // rfo_model (rsirfo.py:1717-1720) with the un-reflected gradient and Hessian: g.s + 0.5 s^T H s in the eigenbasis
-        pred = red.sum(m, [=](int k) { const int i = kidx[k]; const double c = stp[k]; return g0[i] * c + 0.5 * w0[i] * c * c; });
-    }
-    push3(st.predicted, st.n_predicted, pred);
-    st.prev_energy = energy;
-    st.has_prev = 1;
-    st.iteration += 1;
-    st.branch = rr.branch;
-    st.alpha = rr.alpha;
-    st.lambda_aug = rr.lambda_aug0;
-    st.initial_step_norm = rr.initial_norm;
-    st.secular_iters = rr.secular_iters0;
-    st.gradient_norm = gnorm;
-    st.jacobi_sweeps = (einfo[2 * b + 1] & 4) ? -1 : einfo[2 * b];       // -1: solver failure, surfaced as MOPT_E_NUMERIC
-    st.hess_updated = coef ? coef[b].applied : 0;
-    if (lane == 0) states[b] = st;
-    if (dbg && lane == 0 && (b == 0 || b == 15))
-        printf("[rfo_prof] image %d: setup %.1f us, order+filter %.1f us, rs_step %.1f us (branch %d, secular iters %d), rest %.1f us\n", b,
-               (tp1 - tp0) * 0.01, (tp2 - tp1) * 0.01, (tp3 - tp2) * 0.01, rr.branch, rr.secular_iters0, (wall_clock64() - tp3) * 0.01);
+    rfo_scalar_body<false>(n, (int)blockIdx.x, params, states, W, perm, einfo, gt_all_, Bg, Be, coef, coef_out_, dbg, sm);
 }
 
 // out[b][j] = - sum_i coef[b][i] Vt[b][i][j]     grid (ceil(n/64), batch), block 1024: 16 waves share the rows of a

@@ -1,0 +1,568 @@
+// The whole RS-I-RFO step of a SMALL geometry (9 <= n <= 72, i.e. 3 .. 24 atoms) in ONE workgroup and ONE launch (round 3).
+//
+// Reference operation: RSIRFO.run (multioptpy/Optimizer/rsirfo.py:285-490): quasi-Newton update of the Hessian (:1316-1372), TR/rot
+// projection of Hessian and gradient (calc_tools.py:250-293, rsirfo.py:128-190), eigh (:553-657), image function + RS step in the
+// eigenbasis (:404-490, :924-1313), move vector.
+//
+// Why: BASELINE's optmain configurations (7, 11 and 22 atoms) and the images of a 16 x 14 band are latency problems.  The general
+// pipeline (pipeline.hip) needs 30 launches on four streams for such a step -- 0.28 ms of kernels none of which runs longer than 55 us,
+// plus the gaps between them -- and lost to NumPy on one core at n = 21 for the P-RFO class.  Here a geometry is one workgroup of 1024
+// threads, its matrices live in LDS, and the phases below are separated by workgroup barriers instead of kernel boundaries:
+//   A  load; waves 15 / 14 form the TR/rot basis (Gram-Schmidt) and the projected gradient (Householder QR) in registers while
+//      waves 0 .. 13 fetch the Hessian; u = H s; rule coefficients (logic.h, the same code as k_update_coef); H + dH, symmetrised
+//   B  A = sym(H + bias); A -= Q^T W'^T + W' Q  (the rank-12 form of P A P, as k_proj_*)
+//   C  Householder tridiagonalisation: tri_tail_body.hpp on the matrix in LDS (register tiles, two barriers per step)
+//   D  tridiagonal eigenproblem: split at negligible off-diagonals; blocks of at most 12 rows by the one-wave QL (ql_block.hpp),
+//      one wave per block side by side; larger blocks by the in-workgroup divide and conquer (dc_block_body.hpp)
+//   E  ascending order (rank sort), status word
+//   F  V = Q Z: one wave per eigenvector walks the n - 2 reflectors (no barrier: the reflectors are read-only in LDS), and
+//      forms g~_j = v_j . g_proj on the way
+//   G  scalar stage by wave 0: rfo_scalar_body.hpp (the same code as k_rfo_scalar, wave-level barriers)
+//   H  step = - V^T coef
+// The phases re-use the device code of the general pipeline, so the arithmetic is the same up to the order of a few sums; the
+// parity tests of the general pipeline run against this kernel too (MOPT_SMALL=0 switches it off).
+// LDS: a persistent part of 22 n + 36 doubles + 3 n + 8 ints, and a phase part re-used by every phase (largest: the divide and
+// conquer's three m x m tables, 124 KB at n = 72).
+#include <cstdlib>
+
+#include "pipeline.h"
+#include "logic.h"
+#include "tri_tail_body.hpp"
+#include "dc_block_body.hpp"
+#include "rfo_scalar_body.hpp"
+
+namespace mopt {
+
+constexpr int SMALL_MAX = 72;      // = DCB_MAX: the largest block the in-workgroup divide and conquer takes
+constexpr int SMALL_MIN = 9;       // three atoms
+constexpr int SMALL_QL = 12;       // blocks up to this size: one-wave QL (the split the general pipeline uses: dcb_lo - 1, k_tridiag.hip)
+constexpr double SM_EPS = 2.220446049250313e-16;
+constexpr double SM_TINY = 2.2250738585072014e-308;
+
+struct SmallArgs {
+    int n, any_update, any_flow, dbg;
+    const mopt_rsirfo_params *params; mopt_rsirfo_state *states;
+    const double *x, *bg, *g, *px, *pg, *be;
+    const int *rules, *do_update;
+    const double *Hin, *Bias;
+    double *Hsym, *Hinpl, *A, *Zt, *step, *info;
+    UpdateCoef *coef;
+    int *einfo, *sticky;
+};
+
+__device__ __forceinline__ double row16_sum(double v) {      // sum over each 16-lane row, returned to all of its lanes
+    v += dpp_f64z<0xB1>(v);
+    v += dpp_f64z<0x4E>(v);
+    v += dpp_f64z<0x141>(v);
+    v += dpp_f64z<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// TR/rot basis by one wave (k_trrot_basis restated with the rows in registers: lane l holds components l and l + 64)
+__device__ __forceinline__ void small_trrot(int n, const double *x, double *Q, int lane) {
+    const int N = n / 3;
+    double c[3] = {0, 0, 0};
+    for (int a = lane; a < N; a += WAVE) { c[0] += x[3 * a]; c[1] += x[3 * a + 1]; c[2] += x[3 * a + 2]; }
+    const double cx = wave_sum(c[0]) / N, cy = wave_sum(c[1]) / N, cz = wave_sum(c[2]) / N;
+    double raw[6][2], bas[6][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        const bool in = i < n;
+        const int a = in ? i / 3 : 0, cc = i % 3;
+        const double X = x[3 * a] - cx, Y = x[3 * a + 1] - cy, Z = x[3 * a + 2] - cz;
+        raw[0][h] = (in && cc == 0) ? 1.0 : 0.0;
+        raw[1][h] = (in && cc == 1) ? 1.0 : 0.0;
+        raw[2][h] = (in && cc == 2) ? 1.0 : 0.0;
+        raw[3][h] = !in ? 0.0 : (cc == 0) ? 0.0 : (cc == 1 ? -Z : Y);
+        raw[4][h] = !in ? 0.0 : (cc == 0) ? Z : (cc == 1 ? 0.0 : -X);
+        raw[5][h] = !in ? 0.0 : (cc == 0) ? -Y : (cc == 1 ? X : 0.0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) bas[k][h] = 0.0;
+    }
+    int nb = 0;
+#pragma unroll
+    for (int v = 0; v < 6; ++v) {
+        double d[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d[k] = (k < nb) ? wave_sum(raw[v][0] * bas[k][0] + raw[v][1] * bas[k][1]) : 0.0;
+        double w0 = raw[v][0], w1 = raw[v][1];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) if (k < nb) { w0 -= d[k] * bas[k][0]; w1 -= d[k] * bas[k][1]; }
+        const double nrm = sqrt(wave_sum(w0 * w0 + w1 * w1));
+        if (nrm > 1e-10) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) if (k == nb) { bas[k][0] = w0 / nrm; bas[k][1] = w1 / nrm; }
+            ++nb;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (lane < n) Q[k * n + lane] = bas[k][0];
+        if (lane + 64 < n) Q[k * n + lane + 64] = bas[k][1];
+    }
+}
+
+// g - Q Q^T g with Q from the Householder QR of the six raw TR/rot vectors (k_proj_grad, variant 0, restated for one wave)
+__device__ __forceinline__ void small_projgrad(int n, const double *x, const double *g, double *gp, int lane) {
+    const int N = n / 3;
+    double c[3] = {0, 0, 0};
+    for (int a = lane; a < N; a += WAVE) { c[0] += x[3 * a]; c[1] += x[3 * a + 1]; c[2] += x[3 * a + 2]; }
+    const double cx = wave_sum(c[0]) / N, cy = wave_sum(c[1]) / N, cz = wave_sum(c[2]) / N;
+    double col[6][2], t[2], g0[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int i = lane + 64 * h;
+        const bool in = i < n;
+        const int a = in ? i / 3 : 0, cc = i % 3;
+        const double X = x[3 * a] - cx, Y = x[3 * a + 1] - cy, Z = x[3 * a + 2] - cz;
+        col[0][h] = (in && cc == 0) ? 1.0 : 0.0;
+        col[1][h] = (in && cc == 1) ? 1.0 : 0.0;
+        col[2][h] = (in && cc == 2) ? 1.0 : 0.0;
+        col[3][h] = !in ? 0.0 : (cc == 0) ? 0.0 : (cc == 1 ? -Z : Y);
+        col[4][h] = !in ? 0.0 : (cc == 0) ? Z : (cc == 1 ? 0.0 : -X);
+        col[5][h] = !in ? 0.0 : (cc == 0) ? -Y : (cc == 1 ? X : 0.0);
+        g0[h] = in ? g[i] : 0.0;
+        t[h] = g0[h];
+    }
+    double taus[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        // rows behind j (row j sits in lane j, half 0)
+        const double below0 = (lane > j) ? col[j][0] : 0.0;
+        const double xnorm = sqrt(wave_sum(below0 * below0 + col[j][1] * col[j][1]));
+        const double alpha = lane_bcast(col[j][0], j);
+        double tau = 0.0;
+        if (xnorm != 0.0) {
+            const double beta = -copysign(hypot(alpha, xnorm), alpha);
+            tau = (beta - alpha) / beta;
+            const double scal = 1.0 / (alpha - beta);
+            if (lane > j) col[j][0] *= scal;
+            col[j][1] *= scal;
+        }
+        if (lane == j) col[j][0] = 1.0;
+        if (lane < j) col[j][0] = 0.0;                       // (rows in front of j take no part: v_i = 0 there)
+        taus[j] = tau;
+        if (tau != 0.0) {
+#pragma unroll
+            for (int cq = 0; cq < 6; ++cq) {
+                if (cq > j) {
+                    const double d = wave_sum(col[j][0] * col[cq][0] + col[j][1] * col[cq][1]);
+                    // (rows < j of column cq hold R entries: v is zero there, they stay as they are)
+                    col[cq][0] -= tau * col[j][0] * d;
+                    col[cq][1] -= tau * col[j][1] * d;
+                }
+            }
+            const double dt = wave_sum(col[j][0] * t[0] + col[j][1] * t[1]);
+            t[0] -= tau * col[j][0] * dt;
+            t[1] -= tau * col[j][1] * dt;
+        }
+    }
+    // t = [Q^T g ; rest] -> keep the first six entries, then Q t' = H_0 ... H_5 [t'; 0]
+    if (lane >= 6) t[0] = 0.0;
+    t[1] = 0.0;
+#pragma unroll
+    for (int j = 5; j >= 0; --j) {
+        if (taus[j] != 0.0) {
+            const double d = wave_sum(col[j][0] * t[0] + col[j][1] * t[1]);
+            t[0] -= taus[j] * col[j][0] * d;
+            t[1] -= taus[j] * col[j][1] * d;
+        }
+    }
+    if (lane < n) gp[lane] = g0[0] - t[0];
+    if (lane + 64 < n) gp[lane + 64] = g0[1] - t[1];
+}
+
+__host__ __device__ inline size_t small_r0_doubles(int n) { return (size_t)22 * n + 36 + (((size_t)3 * n + 8 + 1) / 2) + 2; }
+__host__ __device__ inline size_t small_aux_doubles(int n) {
+    const size_t vecs = (size_t)22 * n, ch = (n + 63) / 64, tail = 5 * 64 * ch + (size_t)(n - 2) * (n - 1) / 2 + 2;
+    return vecs > tail ? vecs : tail;
+}
+
+template <int CH>
+__global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ UpdateCoef s_coef;
+    __shared__ int s_fail, s_flag;
+    const int n = a.n, nn = n * n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // ---- persistent part
+    double *sx = sm, *sbg = sx + n, *sgp = sbg + n, *sD = sgp + n, *sE = sD + n, *sTAU = sE + n, *sWT = sTAU + n, *sW = sWT + n, *sgt = sW + n,
+           *scf = sgt + n, *sQ = scf + n, *sW6 = sQ + 6 * n, *sM6 = sW6 + 6 * n;
+    int *sperm = (int *)(sM6 + 36), *sbs = sperm + n, *sbe = sbs + n, *seinfo = sbe + n;
+    double *R1 = sm + ((small_r0_doubles(n) + 1) & ~(size_t)1);
+    // ---- phase part, phases A .. C: the matrix, then the vectors of the update (or the tridiagonalisation's tables)
+    double *M = R1, *aux = R1 + nn;
+    double *sg = aux, *spx = sg + n, *spg = spx + n, *ss = spg + n, *sy = ss + n, *su = sy + n, *shy = su + n, *syd = shy + n, *sAv = syd + n;
+    const size_t bn = (size_t)b * n, bnn = (size_t)b * nn;
+    const int do_upd = (a.any_update && (!a.do_update || a.do_update[b])) ? 1 : 0;
+    const int rule = a.rules[b];
+    const bool flow = a.any_flow != 0;
+
+    // ================= A. load, TR/rot basis, projected gradient, Hessian update
+    for (int i = tid; i < n; i += 1024) {
+        sx[i] = a.x[bn + i]; sbg[i] = a.bg[bn + i];
+        if (do_upd) { sg[i] = a.g[bn + i]; spx[i] = a.px[bn + i]; spg[i] = a.pg[bn + i]; }
+    }
+    if (tid == 0) { s_fail = 0; s_flag = 0; }
+    __syncthreads();
+    if (wid == 15) small_trrot(n, sx, sQ, lane);
+    else if (wid == 14) small_projgrad(n, sx, sbg, sgp, lane);
+    else {
+        const double *H = a.Hin + bnn;
+        for (int e = tid; e < nn; e += 896) M[e] = H[e];
+        if (do_upd) for (int i = tid; i < n; i += 896) { ss[i] = sx[i] - spx[i]; sy[i] = sg[i] - spg[i]; }
+    }
+    __syncthreads();
+    if (do_upd) {
+        // u = H s (rows of the unsymmetrised H, as k_matvec) and H y for the flowchart rule: 16 lanes per row
+        const int grp = tid >> 4, l = tid & 15;
+        for (int r = grp; r < n; r += 64) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int j = l; j < n; j += 16) { const double h = M[r * n + j]; a1 += h * ss[j]; if (flow) a2 += h * sy[j]; }
+            a1 = row16_sum(a1);
+            if (flow) a2 = row16_sum(a2);
+            if (l == 0) { su[r] = a1; if (flow) shy[r] = a2; }
+        }
+        __syncthreads();
+        if (wid == 0) {
+            // dots -> rule coefficients (k_update_coef for one wave)
+            double v[4] = {0, 0, 0, 0};
+            for (int i = lane; i < n; i += WAVE) { const double si = ss[i], yi = sy[i], ui = su[i]; v[0] += si * si; v[1] += si * yi; v[2] += yi * yi; v[3] += si * ui; }
+            UpdateDots d;
+            d.ss = wave_sum(v[0]); d.sy = wave_sum(v[1]); d.yy = wave_sum(v[2]); d.su = wave_sum(v[3]);
+            double theta = 1.0;
+            bool damp = false;
+            if (rule_is_dd(rule)) { damp = d.sy < 0.2 * d.ss; theta = dd_theta(d.ss, d.sy, rule_is_block(rule) ? 1e-12 : 1e-10); }
+            double w[5] = {0, 0, 0, 0, 0};
+            for (int i = lane; i < n; i += WAVE) {
+                const double si = ss[i], yi = sy[i], ui = su[i];
+                const double ydi = damp ? theta * yi + (1.0 - theta) * si : yi;
+                const double ai = ydi - ui;
+                syd[i] = ydi; sAv[i] = ai;
+                w[0] += si * ydi; w[1] += ai * ai; w[2] += ai * si;
+                if (flow) { const double zi = yi - shy[i]; w[3] += zi * zi; w[4] += zi * si; }
+            }
+            d.syd = wave_sum(w[0]); d.AA = wave_sum(w[1]); d.As = wave_sum(w[2]); d.zz = wave_sum(w[3]); d.zs = wave_sum(w[4]);
+            if (lane == 0) {
+                const UpdateCoef c = update_coefficients(rule, d, true);
+                s_coef = c;
+                a.coef[b] = c;
+                if (a.info) {
+                    double *o = a.info + (size_t)b * 8;
+                    o[0] = c.applied; o[1] = d.sy; o[2] = d.ss; o[3] = d.yy; o[4] = d.su; o[5] = c.mix; o[6] = c.branch; o[7] = 0.0;
+                }
+            }
+        }
+        __syncthreads();
+    } else {
+        if (tid == 0) {
+            UpdateCoef c; c.c_yy = c.c_uu = c.c_AA = c.c_As = c.c_ss = 0.0; c.applied = 0; c.block_sym = 0; c.mix = 0.0; c.branch = 0;
+            s_coef = c;
+            if (a.any_update) { a.coef[b] = c; if (a.info) for (int k = 0; k < 8; ++k) a.info[(size_t)b * 8 + k] = 0.0; }
+        }
+        __syncthreads();
+    }
+    constexpr int EPT = 6;                                    // 72 * 72 / 1024 rounded up
+    double r1[EPT], r2[EPT];
+    {
+        // H + dH (rank <= 5, symmetric), then 0.5 (X + X^T) (k_apply_update); a skipped update leaves H as it is, not even symmetrised
+        const UpdateCoef c = s_coef;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + 1024 * k;
+            r1[k] = 0.0; r2[k] = 0.0;
+            if (e < nn) {
+                const int i = e / n, j = e - i * n;
+                const double hij = M[e], hji = M[j * n + i];
+                if (c.applied) {
+                    const double yi = syd[i], ui = su[i], ai = sAv[i], si = ss[i], yj = syd[j], uj = su[j], aj = sAv[j], sj = ss[j];
+                    const double dlt = c.c_yy * yi * yj + c.c_uu * ui * uj + c.c_AA * ai * aj + c.c_As * (ai * sj + si * aj) + c.c_ss * si * sj;
+                    double t1 = hij + dlt;
+                    const double t2 = hji + dlt, sym = 0.5 * (t1 + t2);
+                    if (c.block_sym) t1 = sym;
+                    r1[k] = t1; r2[k] = sym;
+                } else { r1[k] = hij; r2[k] = hij; }
+            }
+        }
+        __syncthreads();
+        double *Hs = a.Hsym + bnn, *Hp = a.Hinpl ? a.Hinpl + bnn : nullptr;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + 1024 * k;
+            if (e < nn) { M[e] = r2[k]; Hs[e] = r2[k]; if (Hp) Hp[e] = r1[k]; }
+        }
+        __syncthreads();
+    }
+    // ================= B. A = sym(H + bias), projected
+    {
+        const double *B = a.Bias ? a.Bias + bnn : nullptr;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + 1024 * k;
+            if (e < nn) {
+                const int i = e / n, j = e - i * n;
+                double v = M[e], vt = M[j * n + i];
+                if (B) { v += B[e]; vt += B[j * n + i]; }
+                r1[k] = 0.5 * (v + vt);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { const int e = tid + 1024 * k; if (e < nn) M[e] = r1[k]; }
+        __syncthreads();
+        // W = A Q^T (A is bitwise symmetric: column reads, conflict-free)
+        if (tid < 6 * n) {
+            const int k = tid / n, i = tid - k * n;
+            double acc = 0.0;
+            for (int j = 0; j < n; ++j) acc += M[j * n + i] * sQ[k * n + j];
+            sW6[i * 6 + k] = acc;
+        }
+        __syncthreads();
+        if (tid < 36) {
+            const int k = tid / 6, l = tid - 6 * k;
+            double acc = 0.0;
+            for (int i = 0; i < n; ++i) acc += sQ[k * n + i] * sW6[i * 6 + l];
+            sM6[tid] = acc;
+        }
+        __syncthreads();
+        double wn = 0.0;
+        if (tid < 6 * n) {
+            const int l = tid / n, i = tid - l * n;
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) t += sQ[k * n + i] * 0.5 * (sM6[k * 6 + l] + sM6[l * 6 + k]);
+            wn = sW6[i * 6 + l] - 0.5 * t;
+        }
+        __syncthreads();
+        if (tid < 6 * n) { const int l = tid / n, i = tid - l * n; sW6[i * 6 + l] = wn; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = tid + 1024 * k;
+            if (e < nn) {
+                const int i = e / n, j = e - i * n;
+                double t = 0.0;
+#pragma unroll
+                for (int q = 0; q < 6; ++q) t += sQ[q * n + i] * sW6[j * 6 + q] + sW6[i * 6 + q] * sQ[q * n + j];
+                M[e] -= t;
+            }
+        }
+        __syncthreads();
+    }
+    // ================= C. tridiagonal form (reflectors stay in M, dsytrd layout: row k, columns k + 2 ..)
+    tri_tail_body<CH, 16>(n, -1, 0, M, sD, sE, sTAU, nullptr, aux);
+    __syncthreads();
+    {
+        double *Ag = a.A + bnn;                                // the divide and conquer needs the LDS: the reflectors wait in global memory
+        for (int e = tid; e < nn; e += 1024) Ag[e] = M[e];
+    }
+    // ================= D. eigen-decomposition of the tridiagonal form
+    double *Zt = a.Zt + bnn;
+    {
+        int bad = 0;
+        for (int i = tid; i < n; i += 1024) if (!isfinite(sD[i]) || (i < n - 1 && !isfinite(sE[i]))) bad = 1;
+        bad = __syncthreads_or(bad);
+        if (tid == 0) s_flag = bad;
+        if (!bad) {
+            // splitting (the criterion of k_tri_bisect)
+            double en = 0.0;
+            if (tid < n - 1) { en = sE[tid]; if (fabs(en) <= 32.0 * SM_EPS * (fabs(sD[tid]) + fabs(sD[tid + 1])) || fabs(en) < SM_TINY) en = 0.0; }
+            __syncthreads();
+            if (tid < n) sE[tid] = en;
+            __syncthreads();
+            if (tid < n) {
+                int s = tid; while (s > 0 && sE[s - 1] != 0.0) --s;
+                int t = tid + 1; while (t < n && sE[t - 1] != 0.0) ++t;
+                sbs[tid] = s; sbe[tid] = t;
+            }
+            __syncthreads();
+            // blocks of at most SMALL_QL rows: one wave each, side by side (k_tri_ql32)
+            {
+                double *Zs = R1 + (size_t)wid * 32 * SMALL_QL;
+                int q = 0;
+                for (int s = 0; s < n; ++q) {
+                    const int t = sbe[s], m = t - s;
+                    if (m <= SMALL_QL && (q & 15) == wid) {
+                        if (m == 1) {
+                            if (lane == 0) sWT[s] = sD[s];
+                            for (int i = lane; i < n; i += WAVE) Zt[(size_t)s * n + i] = (i == s) ? 1.0 : 0.0;
+                        } else {
+                            double d = (lane < m) ? sD[s + lane] : 0.0, e = (lane < m - 1) ? sE[s + lane] : 0.0;
+                            const double nrm = wave_max(fmax(fabs(d), fabs(e)));
+                            const double sc = (nrm > 0.0) ? nrm : 1.0;
+                            d /= sc; e /= sc;
+                            for (int c = 0; c < m; ++c) Zs[c * 32 + (lane & 31)] = ((lane & 31) == c) ? 1.0 : 0.0;
+                            wave_sync_lds();
+                            const bool ok = ql_block32(m, d, e, Zs, lane);
+                            wave_sync_lds();
+                            if (!ok && lane == 0) atomicAdd(&s_fail, 1);
+                            if (lane < m) sWT[s + lane] = d * sc;
+                            for (int c = 0; c < m; ++c) {
+                                double *z = Zt + (size_t)(s + c) * n;
+                                for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Zs[c * 32 + (i - s)] : 0.0;
+                            }
+                            wave_sync_lds();
+                        }
+                    }
+                    s = t;
+                }
+            }
+            __syncthreads();
+            // larger blocks: the whole workgroup, one block after the other
+            for (int s = 0; s < n;) {
+                const int t = sbe[s], m = t - s;
+                if (m > SMALL_QL) { dc_block_body(n, s, m, b, sD + s, sE + s, sWT, Zt, &s_fail, R1, 0); __syncthreads(); }
+                s = t;
+            }
+        }
+    }
+    __syncthreads();
+    // ================= E. ascending order, status
+    const int bad = s_flag;
+    {
+        int nf = 0;
+        if (!bad) for (int i = tid; i < n; i += 1024) if (!isfinite(sWT[i])) nf = 1;
+        nf = __syncthreads_or(nf);
+        if (tid < n) {
+            if (bad || nf) { sW[tid] = NAN; sperm[tid] = tid; }
+            else {
+                const double ki = sWT[tid];
+                int rank = 0;
+                for (int j = 0; j < tid; ++j) rank += sWT[j] <= ki;
+                for (int j = tid + 1; j < n; ++j) rank += sWT[j] < ki;
+                sW[rank] = ki; sperm[rank] = tid;
+            }
+        }
+        if (tid == 0) {
+            const int word = (bad || nf) ? 1 : (s_fail ? 4 : 0);
+            seinfo[0] = 0; seinfo[1] = word;
+            a.einfo[2 * b] = 0; a.einfo[2 * b + 1] = word;
+            if (a.sticky && (word & 12)) atomicOr(a.sticky, word & 12);
+            s_flag = (bad || nf) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    const int noeig = s_flag;                                 // non-finite eigen-system: identity fallback (rsirfo.py:365-372)
+    // ================= F. V = Q Z, g~ = V^T g_proj
+    double *MR = R1, *sV = R1 + nn;
+    if (!noeig) {
+        const double *Ag = a.A + bnn;
+        for (int e = tid; e < nn; e += 1024) MR[e] = Ag[e];
+        __syncthreads();
+        // two eigenvectors per wave and pass (independent reduction chains)
+        for (int j0 = wid; j0 < n; j0 += 32) {
+            const int j1 = j0 + 16;
+            const bool two = j1 < n;
+            double z[2][CH];
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = lane + 64 * q;
+                z[0][q] = (c < n) ? Zt[(size_t)j0 * n + c] : 0.0;
+                z[1][q] = (two && c < n) ? Zt[(size_t)j1 * n + c] : 0.0;
+            }
+            for (int k = n - 3; k >= 0; --k) {
+                const double tau = sTAU[k];
+                if (tau == 0.0) continue;
+                double v[CH], p0 = 0.0, p1 = 0.0;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) {
+                    const int c = lane + 64 * q;
+                    v[q] = (c == k + 1) ? 1.0 : ((c > k + 1 && c < n) ? MR[k * n + c] : 0.0);
+                    p0 = fma(v[q], z[0][q], p0); p1 = fma(v[q], z[1][q], p1);
+                }
+                p0 = wave_sum(p0) * tau; p1 = wave_sum(p1) * tau;
+#pragma unroll
+                for (int q = 0; q < CH; ++q) { z[0][q] = fma(-p0, v[q], z[0][q]); z[1][q] = fma(-p1, v[q], z[1][q]); }
+            }
+            double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+            for (int q = 0; q < CH; ++q) {
+                const int c = lane + 64 * q;
+                const double gc = (c < n) ? sgp[c] : 0.0;
+                g0 = fma(z[0][q], gc, g0); g1 = fma(z[1][q], gc, g1);
+                if (c < n) { sV[j0 * n + c] = z[0][q]; if (two) sV[j1 * n + c] = z[1][q]; }
+            }
+            g0 = wave_sum(g0); g1 = wave_sum(g1);
+            if (lane == 0) { sgt[j0] = g0; if (two) sgt[j1] = g1; }
+        }
+    } else {
+        if (tid < n) sgt[tid] = sgp[tid];
+    }
+    __syncthreads();
+    // ================= G. scalar stage (wave 0; its barriers are wave-level)
+    if (wid == 0)
+        rfo_scalar_body<true>(n, 0, a.params + b, a.states + b, sW, sperm, seinfo, sgt, sbg, a.be + b, a.any_update ? a.coef + b : nullptr, scf, 0, R1 + 2 * nn);
+    __syncthreads();
+    // ================= H. step = - sum_i coef_i v_i   (run() returns -move, rsirfo.py:490)
+    if (tid < n) {
+        double out;
+        if (noeig) out = -scf[tid];
+        else {
+            double t0 = 0.0, t1 = 0.0;
+            int i = 0;
+            for (; i + 1 < n; i += 2) {
+                const double c0 = scf[i], c1 = scf[i + 1];
+                t0 = fma(c0, c0 != 0.0 ? sV[i * n + tid] : 0.0, t0);
+                t1 = fma(c1, c1 != 0.0 ? sV[(i + 1) * n + tid] : 0.0, t1);
+            }
+            if (i < n) { const double c0 = scf[i]; t0 = fma(c0, c0 != 0.0 ? sV[i * n + tid] : 0.0, t0); }
+            out = -(t0 + t1);
+        }
+        a.step[bn + tid] = out;
+    }
+}
+
+}  // namespace mopt
+
+int mopt_small_max() {
+    static const int v = [] {
+        const char *e = getenv("MOPT_SMALL");
+        if (e && atoi(e) == 0) return 0;
+        if (getenv("MOPT_EIGH_ALGO")) return 0;              // a forced eigen-solver route means the general pipeline
+        return mopt::SMALL_MAX;
+    }();
+    return v;
+}
+bool mopt_small_eligible(int n) { return n >= mopt::SMALL_MIN && n <= mopt_small_max() && n % 3 == 0; }
+
+// The step of `batch` small geometries, one workgroup each.  Same inputs and outputs as mopt_rsirfo_pipeline (wk.x, bg, g, px, pg, be,
+// params, rules, do_update, states in; states, step, coef, einfo, Hsym, Hinpl out); scratch: wk.A (reflectors), wk.Vt (eigenvectors of the
+// tridiagonal form).
+int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, double *d_Hinpl, double *d_Hsym) {
+    using namespace mopt;
+    if (!mopt_small_eligible(n)) { ctx->err = "mopt_launch_small_rsirfo: n out of range"; return MOPT_E_ARG; }
+    SmallArgs a;
+    a.n = n; a.any_update = any_update ? 1 : 0; a.any_flow = any_flowchart ? 1 : 0; a.dbg = 0;
+    a.params = wk.params; a.states = wk.states;
+    a.x = wk.x; a.bg = wk.bg; a.g = wk.g; a.px = wk.px; a.pg = wk.pg; a.be = wk.be;
+    a.rules = wk.rules; a.do_update = wk.do_update;
+    a.Hin = wk.H; a.Bias = wk.Bias; a.Hsym = d_Hsym; a.Hinpl = d_Hinpl; a.A = wk.A; a.Zt = wk.Vt; a.step = wk.step; a.info = wk.info;
+    a.coef = wk.coef; a.einfo = wk.einfo; a.sticky = wk.sticky;
+    // phase part: max over the phases
+    const size_t nn = (size_t)n * n;
+    const size_t pa = nn + small_aux_doubles(n);
+    const size_t pql = (size_t)16 * 32 * SMALL_QL;
+    const size_t dsmall = (size_t)10 * n * 8 + (size_t)n * sizeof(DcRot) + 8 * 8 + (size_t)8 * n * 4 + 64;
+    const size_t dtabs = (size_t)3 * nn * 8, dleaf = (nn + (size_t)16 * 32 * DCB_LEAF) * 8;
+    const size_t pdc = (dsmall + (dtabs > dleaf ? dtabs : dleaf) + 7) / 8;
+    const size_t pf = 2 * nn + (size_t)15 * n + ((size_t)3 * n + 1) / 2 + 4;
+    size_t ph = pa;
+    if (pql > ph) ph = pql;
+    if (pdc > ph) ph = pdc;
+    if (pf > ph) ph = pf;
+    const size_t lds = (((small_r0_doubles(n) + 1) & ~(size_t)1) + ph + 2) * 8;
+    if (lds > (size_t)ctx->lds_limit - 2048) { ctx->err = "k_small_rsirfo: LDS budget exceeded"; return MOPT_E_ARG; }
+    const void *fn = n <= 64 ? (const void *)k_small_rsirfo<1> : (const void *)k_small_rsirfo<2>;
+    static bool attr_set[64][2] = {};
+    const int dv = ctx->device & 63, vi = n <= 64 ? 0 : 1;
+    if (!attr_set[dv][vi]) {
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 2048));
+        attr_set[dv][vi] = true;
+    }
+    mopt_scope sc(ctx, "small_step", 1);
+    void *args[] = {&a};
+    MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(batch), dim3(1024), args, lds, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
+}

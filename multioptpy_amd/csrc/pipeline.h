@@ -63,6 +63,11 @@ int mopt_launch_fused_update_project(mopt_ctx *ctx, RsirfoWork &wk, int n, int b
 int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart,
                          double *d_Hinpl, double *d_Hsym, bool warm_eigh = false, const mopt::FusedBand *fb = nullptr);
 
+// One-workgroup form of the same step for 9 <= n <= 72 (k_small.hip); taken by mopt_rsirfo_pipeline unless MOPT_SMALL=0 or an eigen-solver
+// route is forced (MOPT_EIGH_ALGO).
+bool mopt_small_eligible(int n);
+int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, double *d_Hinpl, double *d_Hsym);
+
 // Images whose eigen-solve reported a hand-off time-out of the persistent tridiagonalisation (einfo bit 8; k_rfo_scalar leaves their
 // state untouched): A is formed again from the (already updated) Hessian and the image is solved with one launch per Householder
 // step, then the RS-I-RFO stage runs for it.  Synchronises the stream.  wk.x / bg / ... must point at the step's inputs.
