@@ -509,7 +509,7 @@ int mopt_band_step_phase_a(mopt_band *b, int optimize_num) {
         bool fused = fused_env;
         for (char c : b->H_sym) fused = fused && c;
         b->fused_step = fused;
-        if (fused) BTRY(mopt_launch_trrot_basis_side(ctx, n, count, b->X + (size_t)first * n, wk.Q));
+        if (fused && !mopt_small_eligible(n)) BTRY(mopt_launch_trrot_basis_side(ctx, n, count, b->X + (size_t)first * n, wk.Q));      // (small images: k_small.hip forms it itself)
     }
     // (a fill node, not a copy from a host buffer: the step enqueues without waiting for the stream; the fused chain takes the flag as a
     // kernel argument instead)

@@ -48,6 +48,9 @@ struct SmallArgs {
     double *Hsym, *Hinpl, *A, *Zt, *step, *info;
     UpdateCoef *coef;
     int *einfo, *sticky;
+    unsigned long long *done;
+    const double *gamma, *tau;        // Ayala term of the band path: H0 + gamma_b t t^T, t = tau[(tau_first + b) n ..]; null: none
+    int tau_first;
 };
 
 __device__ __forceinline__ double row16_sum(double v) {      // sum over each 16-lane row, returned to all of its lanes
@@ -57,6 +60,8 @@ __device__ __forceinline__ double row16_sum(double v) {      // sum over each 16
     v += dpp_f64z<0x140>(v);
     return v;
 }
+// a product that is rounded on its own (HIP compiles with -ffp-contract=fast: a * b + c would become one FMA)
+__device__ __forceinline__ double sm_mul(double a, double b) { double p = a * b; asm volatile("" : "+v"(p)); return p; }
 __device__ __forceinline__ void wave_sync_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
 
 // TR/rot basis by one wave (k_trrot_basis restated with the rows in registers: lane l holds components l and l + 64)
@@ -198,22 +203,32 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
     const int do_upd = (a.any_update && (!a.do_update || a.do_update[b])) ? 1 : 0;
     const int rule = a.rules[b];
     const bool flow = a.any_flow != 0;
+    long long stamp[12];
+    int nst = 0;
+#define SM_STAMP() do { if (a.dbg && tid == 0) stamp[nst] = wall_clock64(); ++nst; } while (0)
+    SM_STAMP();
 
     // ================= A. load, TR/rot basis, projected gradient, Hessian update
     for (int i = tid; i < n; i += 1024) {
         sx[i] = a.x[bn + i]; sbg[i] = a.bg[bn + i];
         if (do_upd) { sg[i] = a.g[bn + i]; spx[i] = a.px[bn + i]; spg[i] = a.pg[bn + i]; }
+        if (a.gamma) sW6[i] = a.tau[(size_t)(a.tau_first + b) * n + i];      // (the tangent borrows W's space until phase B)
     }
     if (tid == 0) { s_fail = 0; s_flag = 0; }
-    __syncthreads();
+    lds_barrier();
     if (wid == 15) small_trrot(n, sx, sQ, lane);
     else if (wid == 14) small_projgrad(n, sx, sbg, sgp, lane);
     else {
         const double *H = a.Hin + bnn;
-        for (int e = tid; e < nn; e += 896) M[e] = H[e];
+        if (a.gamma) {
+            // band path: the stored Hessian first receives the Ayala curvature term gamma t t^T (k_fused_final's grouping)
+            const double gam = a.gamma[b];
+            for (int e = tid; e < nn; e += 896) { const int i = e / n, j = e - i * n; M[e] = H[e] + sm_mul(gam, sm_mul(sW6[i], sW6[j])); }
+        } else
+            for (int e = tid; e < nn; e += 896) M[e] = H[e];
         if (do_upd) for (int i = tid; i < n; i += 896) { ss[i] = sx[i] - spx[i]; sy[i] = sg[i] - spg[i]; }
     }
-    __syncthreads();
+    lds_barrier();
     if (do_upd) {
         // u = H s (rows of the unsymmetrised H, as k_matvec) and H y for the flowchart rule: 16 lanes per row
         const int grp = tid >> 4, l = tid & 15;
@@ -224,7 +239,7 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
             if (flow) a2 = row16_sum(a2);
             if (l == 0) { su[r] = a1; if (flow) shy[r] = a2; }
         }
-        __syncthreads();
+        lds_barrier();
         if (wid == 0) {
             // dots -> rule coefficients (k_update_coef for one wave)
             double v[4] = {0, 0, 0, 0};
@@ -254,14 +269,14 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
     } else {
         if (tid == 0) {
             UpdateCoef c; c.c_yy = c.c_uu = c.c_AA = c.c_As = c.c_ss = 0.0; c.applied = 0; c.block_sym = 0; c.mix = 0.0; c.branch = 0;
             s_coef = c;
             if (a.any_update) { a.coef[b] = c; if (a.info) for (int k = 0; k < 8; ++k) a.info[(size_t)b * 8 + k] = 0.0; }
         }
-        __syncthreads();
+        lds_barrier();
     }
     constexpr int EPT = 6;                                    // 72 * 72 / 1024 rounded up
     double r1[EPT], r2[EPT];
@@ -277,7 +292,13 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
                 const double hij = M[e], hji = M[j * n + i];
                 if (c.applied) {
                     const double yi = syd[i], ui = su[i], ai = sAv[i], si = ss[i], yj = syd[j], uj = su[j], aj = sAv[j], sj = ss[j];
-                    const double dlt = c.c_yy * yi * yj + c.c_uu * ui * uj + c.c_AA * ai * aj + c.c_As * (ai * sj + si * aj) + c.c_ss * si * sj;
+                    // every product and sum rounded on its own, in an order that is symmetric in (i, j): a bitwise symmetric H stays bitwise
+                    // symmetric (the invariant of the band's resident Hessians, as in k_fused_final)
+                    double dlt = sm_mul(c.c_yy, sm_mul(yi, yj));
+                    dlt = dlt + sm_mul(c.c_uu, sm_mul(ui, uj));
+                    dlt = dlt + sm_mul(c.c_AA, sm_mul(ai, aj));
+                    dlt = dlt + sm_mul(c.c_As, sm_mul(ai, sj) + sm_mul(si, aj));
+                    dlt = dlt + sm_mul(c.c_ss, sm_mul(si, sj));
                     double t1 = hij + dlt;
                     const double t2 = hji + dlt, sym = 0.5 * (t1 + t2);
                     if (c.block_sym) t1 = sym;
@@ -285,15 +306,16 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
                 } else { r1[k] = hij; r2[k] = hij; }
             }
         }
-        __syncthreads();
+        lds_barrier();
         double *Hs = a.Hsym + bnn, *Hp = a.Hinpl ? a.Hinpl + bnn : nullptr;
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = tid + 1024 * k;
             if (e < nn) { M[e] = r2[k]; Hs[e] = r2[k]; if (Hp) Hp[e] = r1[k]; }
         }
-        __syncthreads();
+        lds_barrier();
     }
+    SM_STAMP();
     // ================= B. A = sym(H + bias), projected
     {
         const double *B = a.Bias ? a.Bias + bnn : nullptr;
@@ -307,10 +329,10 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
                 r1[k] = 0.5 * (v + vt);
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < EPT; ++k) { const int e = tid + 1024 * k; if (e < nn) M[e] = r1[k]; }
-        __syncthreads();
+        lds_barrier();
         // W = A Q^T (A is bitwise symmetric: column reads, conflict-free)
         if (tid < 6 * n) {
             const int k = tid / n, i = tid - k * n;
@@ -318,14 +340,14 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
             for (int j = 0; j < n; ++j) acc += M[j * n + i] * sQ[k * n + j];
             sW6[i * 6 + k] = acc;
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 36) {
             const int k = tid / 6, l = tid - 6 * k;
             double acc = 0.0;
             for (int i = 0; i < n; ++i) acc += sQ[k * n + i] * sW6[i * 6 + l];
             sM6[tid] = acc;
         }
-        __syncthreads();
+        lds_barrier();
         double wn = 0.0;
         if (tid < 6 * n) {
             const int l = tid / n, i = tid - l * n;
@@ -334,9 +356,9 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
             for (int k = 0; k < 6; ++k) t += sQ[k * n + i] * 0.5 * (sM6[k * 6 + l] + sM6[l * 6 + k]);
             wn = sW6[i * 6 + l] - 0.5 * t;
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < 6 * n) { const int l = tid / n, i = tid - l * n; sW6[i * 6 + l] = wn; }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             const int e = tid + 1024 * k;
@@ -348,8 +370,9 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
                 M[e] -= t;
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
+    SM_STAMP();
     // ================= C. tridiagonal form (reflectors stay in M, dsytrd layout: row k, columns k + 2 ..)
     tri_tail_body<CH, 16>(n, -1, 0, M, sD, sE, sTAU, nullptr, aux);
     __syncthreads();
@@ -357,6 +380,7 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
         double *Ag = a.A + bnn;                                // the divide and conquer needs the LDS: the reflectors wait in global memory
         for (int e = tid; e < nn; e += 1024) Ag[e] = M[e];
     }
+    SM_STAMP();
     // ================= D. eigen-decomposition of the tridiagonal form
     double *Zt = a.Zt + bnn;
     {
@@ -418,6 +442,7 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
         }
     }
     __syncthreads();
+    SM_STAMP();
     // ================= E. ascending order, status
     const int bad = s_flag;
     {
@@ -444,56 +469,62 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
     }
     __syncthreads();
     const int noeig = s_flag;                                 // non-finite eigen-system: identity fallback (rsirfo.py:365-372)
+    SM_STAMP();
     // ================= F. V = Q Z, g~ = V^T g_proj
     double *MR = R1, *sV = R1 + nn;
     if (!noeig) {
         const double *Ag = a.A + bnn;
         for (int e = tid; e < nn; e += 1024) MR[e] = Ag[e];
         __syncthreads();
-        // two eigenvectors per wave and pass (independent reduction chains)
-        for (int j0 = wid; j0 < n; j0 += 32) {
-            const int j1 = j0 + 16;
-            const bool two = j1 < n;
-            double z[2][CH];
+        // GL lanes per eigenvector (16 for n <= 64, 8 above: every vector of the matrix is in flight in ONE pass), a lane holds components
+        // l, l + GL, ...; a reflector then costs one LDS row read shared by all groups and a reduction over GL lanes only
+        constexpr int GL = (CH == 1) ? 16 : 8, MAXE = (CH == 1) ? 4 : 9, VPW = 64 / GL;
+        const int l = lane & (GL - 1);
+        const int j = wid * VPW + lane / GL;
+        if (j < n) {
+            double z[MAXE];
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int c = lane + 64 * q;
-                z[0][q] = (c < n) ? Zt[(size_t)j0 * n + c] : 0.0;
-                z[1][q] = (two && c < n) ? Zt[(size_t)j1 * n + c] : 0.0;
-            }
+            for (int q = 0; q < MAXE; ++q) { const int c = l + GL * q; z[q] = (c < n) ? Zt[(size_t)j * n + c] : 0.0; }
             for (int k = n - 3; k >= 0; --k) {
                 const double tau = sTAU[k];
                 if (tau == 0.0) continue;
-                double v[CH], p0 = 0.0, p1 = 0.0;
+                double v[MAXE], p = 0.0;
 #pragma unroll
-                for (int q = 0; q < CH; ++q) {
-                    const int c = lane + 64 * q;
+                for (int q = 0; q < MAXE; ++q) {
+                    const int c = l + GL * q;
                     v[q] = (c == k + 1) ? 1.0 : ((c > k + 1 && c < n) ? MR[k * n + c] : 0.0);
-                    p0 = fma(v[q], z[0][q], p0); p1 = fma(v[q], z[1][q], p1);
+                    p = fma(v[q], z[q], p);
                 }
-                p0 = wave_sum(p0) * tau; p1 = wave_sum(p1) * tau;
+                p += dpp_f64z<0xB1>(p);
+                p += dpp_f64z<0x4E>(p);
+                p += dpp_f64z<0x141>(p);
+                if (GL == 16) p += dpp_f64z<0x140>(p);
+                p *= tau;
 #pragma unroll
-                for (int q = 0; q < CH; ++q) { z[0][q] = fma(-p0, v[q], z[0][q]); z[1][q] = fma(-p1, v[q], z[1][q]); }
+                for (int q = 0; q < MAXE; ++q) z[q] = fma(-p, v[q], z[q]);
             }
-            double g0 = 0.0, g1 = 0.0;
+            double gg = 0.0;
 #pragma unroll
-            for (int q = 0; q < CH; ++q) {
-                const int c = lane + 64 * q;
-                const double gc = (c < n) ? sgp[c] : 0.0;
-                g0 = fma(z[0][q], gc, g0); g1 = fma(z[1][q], gc, g1);
-                if (c < n) { sV[j0 * n + c] = z[0][q]; if (two) sV[j1 * n + c] = z[1][q]; }
+            for (int q = 0; q < MAXE; ++q) {
+                const int c = l + GL * q;
+                if (c < n) { gg = fma(z[q], sgp[c], gg); sV[j * n + c] = z[q]; }
             }
-            g0 = wave_sum(g0); g1 = wave_sum(g1);
-            if (lane == 0) { sgt[j0] = g0; if (two) sgt[j1] = g1; }
+            gg += dpp_f64z<0xB1>(gg);
+            gg += dpp_f64z<0x4E>(gg);
+            gg += dpp_f64z<0x141>(gg);
+            if (GL == 16) gg += dpp_f64z<0x140>(gg);
+            if (l == 0) sgt[j] = gg;
         }
     } else {
         if (tid < n) sgt[tid] = sgp[tid];
     }
     __syncthreads();
+    SM_STAMP();
     // ================= G. scalar stage (wave 0; its barriers are wave-level)
     if (wid == 0)
         rfo_scalar_body<true>(n, 0, a.params + b, a.states + b, sW, sperm, seinfo, sgt, sbg, a.be + b, a.any_update ? a.coef + b : nullptr, scf, 0, R1 + 2 * nn);
-    __syncthreads();
+    lds_barrier();
+    SM_STAMP();
     // ================= H. step = - sum_i coef_i v_i   (run() returns -move, rsirfo.py:490)
     if (tid < n) {
         double out;
@@ -511,6 +542,18 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
         }
         a.step[bn + tid] = out;
     }
+    SM_STAMP();
+    if (a.done) {
+        // results may sit in host memory the caller polls (mopt_rsirfo_run): every thread's stores first, then the counter
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (a.dbg && tid == 0 && b == 0)
+        printf("[small] n=%d: A update %.1f, B project %.1f, C tridiag %.1f, D eigen %.1f, E sort %.1f, F backtransform %.1f, G scalar %.1f, H step %.1f us\n", n,
+               (stamp[1] - stamp[0]) * 0.01, (stamp[2] - stamp[1]) * 0.01, (stamp[3] - stamp[2]) * 0.01, (stamp[4] - stamp[3]) * 0.01, (stamp[5] - stamp[4]) * 0.01,
+               (stamp[6] - stamp[5]) * 0.01, (stamp[7] - stamp[6]) * 0.01, (stamp[8] - stamp[7]) * 0.01);
+#undef SM_STAMP
 }
 
 }  // namespace mopt
@@ -526,19 +569,21 @@ int mopt_small_max() {
 }
 bool mopt_small_eligible(int n) { return n >= mopt::SMALL_MIN && n <= mopt_small_max() && n % 3 == 0; }
 
-// The step of `batch` small geometries, one workgroup each.  Same inputs and outputs as mopt_rsirfo_pipeline (wk.x, bg, g, px, pg, be,
-// params, rules, do_update, states in; states, step, coef, einfo, Hsym, Hinpl out); scratch: wk.A (reflectors), wk.Vt (eigenvectors of the
-// tridiagonal form).
-int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, double *d_Hinpl, double *d_Hsym) {
+// The step of `batch` small geometries, one workgroup each.  Same inputs and outputs as mopt_rsirfo_pipeline; `io` names them (device
+// or device-visible host memory), wk supplies the scratch: wk.A (reflectors), wk.Vt (eigenvectors of the tridiagonal form), coef, info,
+// einfo, sticky.
+int mopt_launch_small_rsirfo_io(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, const SmallStepIO &io) {
     using namespace mopt;
     if (!mopt_small_eligible(n)) { ctx->err = "mopt_launch_small_rsirfo: n out of range"; return MOPT_E_ARG; }
     SmallArgs a;
-    a.n = n; a.any_update = any_update ? 1 : 0; a.any_flow = any_flowchart ? 1 : 0; a.dbg = 0;
-    a.params = wk.params; a.states = wk.states;
-    a.x = wk.x; a.bg = wk.bg; a.g = wk.g; a.px = wk.px; a.pg = wk.pg; a.be = wk.be;
-    a.rules = wk.rules; a.do_update = wk.do_update;
-    a.Hin = wk.H; a.Bias = wk.Bias; a.Hsym = d_Hsym; a.Hinpl = d_Hinpl; a.A = wk.A; a.Zt = wk.Vt; a.step = wk.step; a.info = wk.info;
-    a.coef = wk.coef; a.einfo = wk.einfo; a.sticky = wk.sticky;
+    static const int dbg = getenv("MOPT_SMALL_DBG") ? 1 : 0;
+    a.n = n; a.any_update = any_update ? 1 : 0; a.any_flow = any_flowchart ? 1 : 0; a.dbg = dbg;
+    a.params = io.params; a.states = io.states;
+    a.x = io.x; a.bg = io.bg; a.g = io.g; a.px = io.px; a.pg = io.pg; a.be = io.be;
+    a.rules = io.rules; a.do_update = io.do_update;
+    a.Hin = io.Hin; a.Bias = io.Bias; a.Hsym = io.Hsym; a.Hinpl = io.Hinpl; a.A = wk.A; a.Zt = wk.Vt; a.step = io.step; a.info = wk.info;
+    a.coef = wk.coef; a.einfo = wk.einfo; a.sticky = wk.sticky; a.done = io.done;
+    a.gamma = io.gamma; a.tau = io.tau; a.tau_first = io.tau_first;
     // phase part: max over the phases
     const size_t nn = (size_t)n * n;
     const size_t pa = nn + small_aux_doubles(n);
@@ -565,4 +610,15 @@ int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bo
     MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(batch), dim3(1024), args, lds, ctx->stream));
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
+}
+
+int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, double *d_Hinpl, double *d_Hsym,
+                             const mopt::FusedBand *fb) {
+    SmallStepIO io;
+    io.gamma = fb ? fb->gamma : nullptr; io.tau = fb ? fb->tau : nullptr; io.tau_first = fb ? fb->first : 0;
+    io.params = wk.params; io.states = wk.states;
+    io.x = wk.x; io.bg = wk.bg; io.g = wk.g; io.px = wk.px; io.pg = wk.pg; io.be = wk.be;
+    io.rules = wk.rules; io.do_update = fb ? nullptr : wk.do_update;      // (band, fused form: every image updates, or none)
+    io.Hin = wk.H; io.Bias = wk.Bias; io.Hsym = d_Hsym; io.Hinpl = d_Hinpl; io.step = wk.step; io.done = nullptr;
+    return mopt_launch_small_rsirfo_io(ctx, wk, n, batch, any_update, any_flowchart, io);
 }

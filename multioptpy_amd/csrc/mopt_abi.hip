@@ -1,4 +1,5 @@
 // C ABI of libmopt_hip.so (see include/mopt_hip.h): context, workspaces and the host-pointer entry points.
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -534,6 +535,76 @@ static int ws_get(mopt_ctx *ctx, int n, int batch, bool own_h, bool bias, bool i
     return MOPT_OK;
 }
 
+// Small geometries (k_small.hip): the kernel reads its inputs from, and writes its results to, one pinned host span it can address, and
+// the host waits for the kernel's completion counter in that span instead of for the stream -- no copy command and no stream wake-up
+// on the path (five copies and the synchronisation were 40 us of a 195 us call at n = 21).  Span: [inputs | states | step | H | bias |
+// Hsym | Hinpl | counter].
+static int rsirfo_run_small(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
+                            const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                            const double *pre_g, const double *B_e, double *step, double *H_inplace, double *H_sym, const std::vector<int> &rules,
+                            const std::vector<int> &upd, bool any_upd, bool any_flow) {
+    const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
+    auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    RsirfoWork *wkp = nullptr;
+    void *io_p = nullptr;
+    TRY(ws_get(ctx, n, batch, true, false, false, 256, &wkp, &io_p));
+    RsirfoWork &wk = *wkp;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes); return o; };
+    const size_t o_x = take(nv), o_bg = take(nv), o_g = take(nv), o_px = take(nv), o_pg = take(nv), o_be = take(batch * sizeof(double)),
+                 o_par = take(batch * sizeof(mopt_rsirfo_params)), o_rul = take(batch * sizeof(int)), o_upd = take(batch * sizeof(int)),
+                 o_st = take(batch * sizeof(mopt_rsirfo_state)), o_step = take(nv), o_H = take(nn), o_B = bias_hessian ? take(nn) : 0,
+                 o_Hs = take(nn), o_Hp = H_inplace ? take(nn) : 0, o_done = take(64);
+    char *pin = (char *)pin_get(ctx, off);
+    if (!pin) { ctx->err = "hipHostMalloc failed (staging buffer)"; return MOPT_E_NOMEM; }
+    char *dpin = nullptr;
+    MOPT_HIP_TRY(ctx, hipHostGetDevicePointer((void **)&dpin, pin, 0));
+    const bool have_prev = pre_geom && pre_g;
+    std::memcpy(pin + o_x, geom, nv); std::memcpy(pin + o_bg, B_g, nv); std::memcpy(pin + o_g, g ? g : B_g, nv);
+    if (have_prev) { std::memcpy(pin + o_px, pre_geom, nv); std::memcpy(pin + o_pg, pre_g, nv); }
+    std::memcpy(pin + o_be, B_e, batch * sizeof(double));
+    std::memcpy(pin + o_par, params, batch * sizeof(mopt_rsirfo_params));
+    std::memcpy(pin + o_rul, rules.data(), batch * sizeof(int));
+    std::memcpy(pin + o_upd, upd.data(), batch * sizeof(int));
+    std::memcpy(pin + o_st, state, batch * sizeof(mopt_rsirfo_state));
+    std::memcpy(pin + o_H, hessian, nn);
+    if (bias_hessian) std::memcpy(pin + o_B, bias_hessian, nn);
+    volatile unsigned long long *done = (volatile unsigned long long *)(pin + o_done);
+    *done = 0ull;
+    SmallStepIO io;
+    io.params = (const mopt_rsirfo_params *)(dpin + o_par); io.states = (mopt_rsirfo_state *)(dpin + o_st);
+    io.x = (const double *)(dpin + o_x); io.bg = (const double *)(dpin + o_bg); io.g = (const double *)(dpin + o_g);
+    io.px = (const double *)(dpin + o_px); io.pg = (const double *)(dpin + o_pg); io.be = (const double *)(dpin + o_be);
+    io.rules = (const int *)(dpin + o_rul); io.do_update = (const int *)(dpin + o_upd);
+    io.Hin = (const double *)(dpin + o_H); io.Bias = bias_hessian ? (const double *)(dpin + o_B) : nullptr;
+    io.Hsym = (double *)(dpin + o_Hs); io.Hinpl = H_inplace ? (double *)(dpin + o_Hp) : nullptr;
+    io.step = (double *)(dpin + o_step); io.done = (unsigned long long *)(dpin + o_done);
+    TRY(mopt_launch_small_rsirfo_io(ctx, wk, n, batch, any_upd, any_flow, io));
+    {
+        // wait for the counter (bounded: a kernel that never finishes would otherwise hang the caller without a message)
+        static const bool no_poll = getenv("MOPT_SMALL_NOPOLL") != nullptr;
+        bool seen = false;
+        if (!no_poll) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (long it = 0;; ++it) {
+                if (__atomic_load_n((const unsigned long long *)done, __ATOMIC_ACQUIRE) >= (unsigned long long)batch) { seen = true; break; }
+                if ((it & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) break;
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+        }
+        if (!seen) MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    std::memcpy(state, pin + o_st, batch * sizeof(mopt_rsirfo_state));
+    std::memcpy(step, pin + o_step, nv);
+    if (H_sym) std::memcpy(H_sym, pin + o_Hs, nn);
+    if (H_inplace) std::memcpy(H_inplace, pin + o_Hp, nn);
+    for (int b = 0; b < batch; ++b)
+        if (state[b].jacobi_sweeps < 0) { ctx->err = "mopt_rsirfo_run: the eigen-solver failed"; return MOPT_E_NUMERIC; }
+    return MOPT_OK;
+}
+
 extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *params, mopt_rsirfo_state *state,
                                const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
                                const double *g, const double *pre_geom, const double *pre_g, const double *B_e, double *step,
@@ -544,6 +615,19 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
     hipSetDevice(ctx->device);
     const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
     auto al = [](size_t bytes) { return (bytes + 255) & ~(size_t)255; };
+    const bool have_prev = pre_geom && pre_g;
+    std::vector<int> rules(batch), upd(batch);
+    bool any_flow = false, any_upd = false;
+    for (int b = 0; b < batch; ++b) {
+        rules[b] = params[b].rule;
+        if (rules[b] < 0 || rules[b] >= MOPT_RULE_COUNT) { ctx->err = "unknown update rule"; return MOPT_E_ARG; }
+        upd[b] = (have_prev && state[b].has_prev) ? 1 : 0;       // rsirfo.py:308
+        any_flow |= (rules[b] == MOPT_RULE_FLOWCHART);
+        any_upd |= upd[b] != 0;
+    }
+    if (mopt_small_eligible(n) && !mopt_debug_poison_on() && (size_t)batch * n * n * sizeof(double) <= ((size_t)4 << 20))
+        return rsirfo_run_small(ctx, n, batch, params, state, hessian, bias_hessian, geom, B_g, g, pre_geom, pre_g, B_e, step, H_inplace, H_sym, rules, upd,
+                                any_upd, any_flow);
     const size_t io_tot = 6 * al(nv) + al(batch * sizeof(double)) + al(batch * sizeof(mopt_rsirfo_params)) + 2 * al(batch * sizeof(int)) +
                           al(batch * sizeof(mopt_rsirfo_state));
     // workspace + I/O span: cached per shape, or fresh (poisoned, guarded) in the debug mode
@@ -563,16 +647,6 @@ extern "C" int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirf
     struct Restore { RsirfoWork &w; double *x, *bg, *g, *px, *pg, *be, *step; mopt_rsirfo_params *params; int *rules, *do_update; mopt_rsirfo_state *states;
                      ~Restore() { w.x = x; w.bg = bg; w.g = g; w.px = px; w.pg = pg; w.be = be; w.step = step; w.params = params; w.rules = rules; w.do_update = do_update; w.states = states; } }
         restore{wk, wk.x, wk.bg, wk.g, wk.px, wk.pg, wk.be, wk.step, wk.params, wk.rules, wk.do_update, wk.states};
-    const bool have_prev = pre_geom && pre_g;
-    std::vector<int> rules(batch), upd(batch);
-    bool any_flow = false, any_upd = false;
-    for (int b = 0; b < batch; ++b) {
-        rules[b] = params[b].rule;
-        if (rules[b] < 0 || rules[b] >= MOPT_RULE_COUNT) { ctx->err = "unknown update rule"; return MOPT_E_ARG; }
-        upd[b] = (have_prev && state[b].has_prev) ? 1 : 0;       // rsirfo.py:308
-        any_flow |= (rules[b] == MOPT_RULE_FLOWCHART);
-        any_upd |= upd[b] != 0;
-    }
     // The small inputs travel as ONE copy from a pinned staging buffer into one device span, the outputs [states | step] and -- up to
     // 1 MB each -- the Hessians come back through it as well, so no copy of the call blocks on pageable memory before the final
     // synchronisation (twelve small pageable copies in and four out were 130 us of a 0.5 ms call).  The span replaces the workspace's

@@ -66,7 +66,21 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
 // One-workgroup form of the same step for 9 <= n <= 72 (k_small.hip); taken by mopt_rsirfo_pipeline unless MOPT_SMALL=0 or an eigen-solver
 // route is forced (MOPT_EIGH_ALGO).
 bool mopt_small_eligible(int n);
-int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, double *d_Hinpl, double *d_Hsym);
+int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, double *d_Hinpl, double *d_Hsym,
+                             const mopt::FusedBand *fb = nullptr);
+// The same with the inputs and outputs named one by one: any of them may be host memory the device can address (hipHostMalloc), which is how
+// mopt_rsirfo_run avoids its copies for these sizes.  done: counter incremented once per geometry behind its last store (system scope), or null.
+struct SmallStepIO {
+    const mopt_rsirfo_params *params; mopt_rsirfo_state *states;
+    const double *x, *bg, *g, *px, *pg, *be;
+    const int *rules, *do_update;
+    const double *Hin, *Bias;
+    double *Hsym, *Hinpl, *step;
+    unsigned long long *done;
+    const double *gamma = nullptr, *tau = nullptr;   // band path: Ayala term gamma_b t t^T added to the stored Hessian first (FusedBand)
+    int tau_first = 0;
+};
+int mopt_launch_small_rsirfo_io(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, const SmallStepIO &io);
 
 // Images whose eigen-solve reported a hand-off time-out of the persistent tridiagonalisation (einfo bit 8; k_rfo_scalar leaves their
 // state untouched): A is formed again from the (already updated) Hessian and the image is solved with one launch per Householder

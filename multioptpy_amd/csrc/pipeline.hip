@@ -94,7 +94,7 @@ int mopt_rsirfo_pipeline(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool a
     int rc;
     const mopt::UpdateCoef *coef = nullptr;
     // small geometries: the whole step in one workgroup and one launch (k_small.hip)
-    if (!fb && !warm_eigh && mopt_small_eligible(n)) return mopt_launch_small_rsirfo(ctx, wk, n, batch, any_update, any_flowchart, d_Hinpl, d_Hsym);
+    if (mopt_small_eligible(n)) return mopt_launch_small_rsirfo(ctx, wk, n, batch, any_update, any_flowchart, d_Hinpl, d_Hsym, fb);
     if (!fb) {                                               // (fused band path: already forked by the band, ahead of its force kernel)
         rc = mopt_launch_trrot_basis_side(ctx, n, batch, wk.x, wk.Q);                                // joined in front of k_proj_w
         if (rc != MOPT_OK) return rc;
