@@ -215,11 +215,11 @@ struct mopt_ctx {
 struct mopt_scope {
     mopt_ctx *c; const char *name; hipEvent_t a = nullptr, b = nullptr; int n; hipStream_t st;
     mopt_scope(mopt_ctx *ctx, const char *nm, int nlaunch = 1, hipStream_t on = nullptr) : c(ctx), name(nm), n(nlaunch), st(on ? on : ctx->stream) {
-        if (c->timing) { hipEventCreate(&a); hipEventCreate(&b); hipEventRecord(a, st); }
+        if (c->timing) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, st); }
     }
     ~mopt_scope() {
         if (c->timing) {
-            hipEventRecord(b, st);
+            (void)hipEventRecord(b, st);
             auto &t = c->timers[name];
             t.ev.emplace_back(a, b);
             t.launches += n;

@@ -21,7 +21,7 @@
 //   H  step = - V^T coef
 // The phases re-use the device code of the general pipeline, so the arithmetic is the same up to the order of a few sums; the
 // parity tests of the general pipeline run against this kernel too (MOPT_SMALL=0 switches it off).
-// LDS: a persistent part of 22 n + 36 doubles + 3 n + 8 ints, and a phase part re-used by every phase (largest: the divide and
+// LDS: a persistent part of 24 n + 36 doubles + 3 n + 8 ints, and a phase part re-used by every phase (largest: the divide and
 // conquer's three m x m tables, 124 KB at n = 72).
 #include <cstdlib>
 
@@ -30,6 +30,7 @@
 #include "tri_tail_body.hpp"
 #include "dc_block_body.hpp"
 #include "rfo_scalar_body.hpp"
+#include "prfo_body.hpp"
 
 namespace mopt {
 
@@ -110,7 +111,9 @@ __device__ __forceinline__ void small_trrot(int n, const double *x, double *Q, i
 }
 
 // g - Q Q^T g with Q from the Householder QR of the six raw TR/rot vectors (k_proj_grad, variant 0, restated for one wave)
-__device__ __forceinline__ void small_projgrad(int n, const double *x, const double *g, double *gp, int lane) {
+// VARIANT 1 (rsprfo.py:245-281): the columns of Q whose R diagonal is not above 1e-10 are dropped; returns |g_proj|.
+template <int VARIANT>
+__device__ __forceinline__ double small_projgrad(int n, const double *x, const double *g, double *gp, int lane) {
     const int N = n / 3;
     double c[3] = {0, 0, 0};
     for (int a = lane; a < N; a += WAVE) { c[0] += x[3 * a]; c[1] += x[3 * a + 1]; c[2] += x[3 * a + 2]; }
@@ -131,7 +134,7 @@ __device__ __forceinline__ void small_projgrad(int n, const double *x, const dou
         g0[h] = in ? g[i] : 0.0;
         t[h] = g0[h];
     }
-    double taus[6];
+    double taus[6], rdiag[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         // rows behind j (row j sits in lane j, half 0)
@@ -139,8 +142,10 @@ __device__ __forceinline__ void small_projgrad(int n, const double *x, const dou
         const double xnorm = sqrt(wave_sum(below0 * below0 + col[j][1] * col[j][1]));
         const double alpha = lane_bcast(col[j][0], j);
         double tau = 0.0;
+        rdiag[j] = alpha;
         if (xnorm != 0.0) {
             const double beta = -copysign(hypot(alpha, xnorm), alpha);
+            rdiag[j] = beta;
             tau = (beta - alpha) / beta;
             const double scal = 1.0 / (alpha - beta);
             if (lane > j) col[j][0] *= scal;
@@ -167,6 +172,10 @@ __device__ __forceinline__ void small_projgrad(int n, const double *x, const dou
     // t = [Q^T g ; rest] -> keep the first six entries, then Q t' = H_0 ... H_5 [t'; 0]
     if (lane >= 6) t[0] = 0.0;
     t[1] = 0.0;
+    if (VARIANT == 1) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) if (lane == j && !(fabs(rdiag[j]) > 1e-10)) t[0] = 0.0;
+    }
 #pragma unroll
     for (int j = 5; j >= 0; --j) {
         if (taus[j] != 0.0) {
@@ -175,26 +184,251 @@ __device__ __forceinline__ void small_projgrad(int n, const double *x, const dou
             t[1] -= taus[j] * col[j][1] * d;
         }
     }
-    if (lane < n) gp[lane] = g0[0] - t[0];
-    if (lane + 64 < n) gp[lane + 64] = g0[1] - t[1];
+    const double o0 = g0[0] - t[0], o1 = g0[1] - t[1];
+    if (lane < n) gp[lane] = o0;
+    if (lane + 64 < n) gp[lane + 64] = o1;
+    return sqrt(wave_sum((lane < n ? o0 * o0 : 0.0) + (lane + 64 < n ? o1 * o1 : 0.0)));
 }
 
-__host__ __device__ inline size_t small_r0_doubles(int n) { return (size_t)22 * n + 36 + (((size_t)3 * n + 8 + 1) / 2) + 2; }
+__host__ __device__ inline size_t small_r0_doubles(int n) { return (size_t)24 * n + 36 + (((size_t)3 * n + 8 + 1) / 2) + 2; }
 __host__ __device__ inline size_t small_aux_doubles(int n) {
     const size_t vecs = (size_t)22 * n, ch = (n + 63) / 64, tail = 5 * 64 * ch + (size_t)(n - 2) * (n - 1) / 2 + 2;
     return vecs > tail ? vecs : tail;
+}
+
+// M (LDS, n x n) <- 0.5 ((M + B) + (M + B)^T), then (project) M -= Q^T W'^T + W' Q = P M P with the six TR/rot vectors in sQ (k_sym_add,
+// k_proj_w / fix / apply restated for one workgroup).  B: n x n in global memory, or null.
+__device__ __forceinline__ void small_sym_project(int n, double *M, const double *B, const double *sQ, double *sW6, double *sM6, bool project) {
+    constexpr int EPT = 6;
+    const int nn = n * n, tid = threadIdx.x;
+    double r1[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + 1024 * k;
+        if (e < nn) {
+            const int i = e / n, j = e - i * n;
+            double v = M[e], vt = M[j * n + i];
+            if (B) { v += B[e]; vt += B[j * n + i]; }
+            r1[k] = 0.5 * (v + vt);
+        }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) { const int e = tid + 1024 * k; if (e < nn) M[e] = r1[k]; }
+    lds_barrier();
+    if (!project) return;
+    // W = A Q^T (A is bitwise symmetric: column reads, conflict-free)
+    if (tid < 6 * n) {
+        const int k = tid / n, i = tid - k * n;
+        double acc = 0.0;
+        for (int j = 0; j < n; ++j) acc += M[j * n + i] * sQ[k * n + j];
+        sW6[i * 6 + k] = acc;
+    }
+    lds_barrier();
+    if (tid < 36) {
+        const int k = tid / 6, l = tid - 6 * k;
+        double acc = 0.0;
+        for (int i = 0; i < n; ++i) acc += sQ[k * n + i] * sW6[i * 6 + l];
+        sM6[tid] = acc;
+    }
+    lds_barrier();
+    double wn = 0.0;
+    if (tid < 6 * n) {
+        const int l = tid / n, i = tid - l * n;
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t += sQ[k * n + i] * 0.5 * (sM6[k * 6 + l] + sM6[l * 6 + k]);
+        wn = sW6[i * 6 + l] - 0.5 * t;
+    }
+    lds_barrier();
+    if (tid < 6 * n) { const int l = tid / n, i = tid - l * n; sW6[i * 6 + l] = wn; }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int e = tid + 1024 * k;
+        if (e < nn) {
+            const int i = e / n, j = e - i * n;
+            double t = 0.0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) t += sQ[q * n + i] * sW6[j * 6 + q] + sW6[i * 6 + q] * sQ[q * n + j];
+            M[e] -= t;
+        }
+    }
+    lds_barrier();
+}
+
+// Phases C .. F for the symmetric matrix in M (LDS, n x n): on return sW / sperm hold the ascending eigenvalues and their vector rows,
+// sV = R1 + n n the eigenvectors (row j = vector j, unsorted), sgt[j] = v_j . sgp and, with v2, o2[j] = v_j . v2; seinfo / einfo_g the status
+// words.  Returns 1 when the eigen-system is not finite (identity fallback: sgt = sgp, o2 = v2).  Ag, Ztg: n x n scratch in global memory.
+template <int CH>
+__device__ __forceinline__ int small_eigen(int n, int b, double *M, double *aux, double *R1, double *sD, double *sE, double *sTAU, double *sWT, double *sW,
+                                           int *sperm, int *sbs, int *sbe, int *seinfo, double *Ag, double *Ztg, int *einfo_g, int *sticky,
+                                           const double *sgp, double *sgt, const double *v2, double *o2) {
+    __shared__ int s_fail, s_flag;
+    const int nn = n * n, tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) { s_fail = 0; s_flag = 0; }
+    // ================= C. tridiagonal form (reflectors stay in M, dsytrd layout: row k, columns k + 2 ..)
+    tri_tail_body<CH, 16>(n, -1, 0, M, sD, sE, sTAU, nullptr, aux);
+    __syncthreads();
+    {
+        // (the divide and conquer needs the LDS: the reflectors wait in global memory)
+        for (int e = tid; e < nn; e += 1024) Ag[e] = M[e];
+    }
+    // ================= D. eigen-decomposition of the tridiagonal form
+    double *Zt = Ztg;
+    {
+        int bad = 0;
+        for (int i = tid; i < n; i += 1024) if (!isfinite(sD[i]) || (i < n - 1 && !isfinite(sE[i]))) bad = 1;
+        bad = __syncthreads_or(bad);
+        if (tid == 0) s_flag = bad;
+        if (!bad) {
+            // splitting (the criterion of k_tri_bisect)
+            double en = 0.0;
+            if (tid < n - 1) { en = sE[tid]; if (fabs(en) <= 32.0 * SM_EPS * (fabs(sD[tid]) + fabs(sD[tid + 1])) || fabs(en) < SM_TINY) en = 0.0; }
+            __syncthreads();
+            if (tid < n) sE[tid] = en;
+            __syncthreads();
+            if (tid < n) {
+                int s = tid; while (s > 0 && sE[s - 1] != 0.0) --s;
+                int t = tid + 1; while (t < n && sE[t - 1] != 0.0) ++t;
+                sbs[tid] = s; sbe[tid] = t;
+            }
+            __syncthreads();
+            // blocks of at most SMALL_QL rows: one wave each, side by side (k_tri_ql32)
+            {
+                double *Zs = R1 + (size_t)wid * 32 * SMALL_QL;
+                int q = 0;
+                for (int s = 0; s < n; ++q) {
+                    const int t = sbe[s], m = t - s;
+                    if (m <= SMALL_QL && (q & 15) == wid) {
+                        if (m == 1) {
+                            if (lane == 0) sWT[s] = sD[s];
+                            for (int i = lane; i < n; i += WAVE) Zt[(size_t)s * n + i] = (i == s) ? 1.0 : 0.0;
+                        } else {
+                            double d = (lane < m) ? sD[s + lane] : 0.0, e = (lane < m - 1) ? sE[s + lane] : 0.0;
+                            const double nrm = wave_max(fmax(fabs(d), fabs(e)));
+                            const double sc = (nrm > 0.0) ? nrm : 1.0;
+                            d /= sc; e /= sc;
+                            for (int c = 0; c < m; ++c) Zs[c * 32 + (lane & 31)] = ((lane & 31) == c) ? 1.0 : 0.0;
+                            wave_sync_lds();
+                            const bool ok = ql_block32(m, d, e, Zs, lane);
+                            wave_sync_lds();
+                            if (!ok && lane == 0) atomicAdd(&s_fail, 1);
+                            if (lane < m) sWT[s + lane] = d * sc;
+                            for (int c = 0; c < m; ++c) {
+                                double *z = Zt + (size_t)(s + c) * n;
+                                for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Zs[c * 32 + (i - s)] : 0.0;
+                            }
+                            wave_sync_lds();
+                        }
+                    }
+                    s = t;
+                }
+            }
+            __syncthreads();
+            // larger blocks: the whole workgroup, one block after the other
+            for (int s = 0; s < n;) {
+                const int t = sbe[s], m = t - s;
+                if (m > SMALL_QL) { dc_block_body(n, s, m, b, sD + s, sE + s, sWT, Zt, &s_fail, R1, 0); __syncthreads(); }
+                s = t;
+            }
+        }
+    }
+    __syncthreads();
+    // ================= E. ascending order, status
+    const int bad = s_flag;
+    {
+        int nf = 0;
+        if (!bad) for (int i = tid; i < n; i += 1024) if (!isfinite(sWT[i])) nf = 1;
+        nf = __syncthreads_or(nf);
+        if (tid < n) {
+            if (bad || nf) { sW[tid] = NAN; sperm[tid] = tid; }
+            else {
+                const double ki = sWT[tid];
+                int rank = 0;
+                for (int j = 0; j < tid; ++j) rank += sWT[j] <= ki;
+                for (int j = tid + 1; j < n; ++j) rank += sWT[j] < ki;
+                sW[rank] = ki; sperm[rank] = tid;
+            }
+        }
+        if (tid == 0) {
+            const int word = (bad || nf) ? 1 : (s_fail ? 4 : 0);
+            seinfo[0] = 0; seinfo[1] = word;
+            einfo_g[0] = 0; einfo_g[1] = word;
+            if (sticky && (word & 12)) atomicOr(sticky, word & 12);
+            s_flag = (bad || nf) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    const int noeig = s_flag;                                 // non-finite eigen-system: identity fallback (rsirfo.py:365-372, rsprfo.py:786-790)
+    // ================= F. V = Q Z, g~ = V^T g_proj
+    double *MR = R1, *sV = R1 + nn;
+    if (!noeig) {
+        for (int e = tid; e < nn; e += 1024) MR[e] = Ag[e];
+        __syncthreads();
+        // GL lanes per eigenvector (16 for n <= 64, 8 above: every vector of the matrix is in flight in ONE pass), a lane holds components
+        // l, l + GL, ...; a reflector then costs one LDS row read shared by all groups and a reduction over GL lanes only
+        constexpr int GL = (CH == 1) ? 16 : 8, MAXE = (CH == 1) ? 4 : 9, VPW = 64 / GL;
+        const int l = lane & (GL - 1);
+        const int j = wid * VPW + lane / GL;
+        if (j < n) {
+            double z[MAXE];
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) { const int c = l + GL * q; z[q] = (c < n) ? Zt[(size_t)j * n + c] : 0.0; }
+            for (int k = n - 3; k >= 0; --k) {
+                const double tau = sTAU[k];
+                if (tau == 0.0) continue;
+                double v[MAXE], p = 0.0;
+#pragma unroll
+                for (int q = 0; q < MAXE; ++q) {
+                    const int c = l + GL * q;
+                    v[q] = (c == k + 1) ? 1.0 : ((c > k + 1 && c < n) ? MR[k * n + c] : 0.0);
+                    p = fma(v[q], z[q], p);
+                }
+                p += dpp_f64z<0xB1>(p);
+                p += dpp_f64z<0x4E>(p);
+                p += dpp_f64z<0x141>(p);
+                if (GL == 16) p += dpp_f64z<0x140>(p);
+                p *= tau;
+#pragma unroll
+                for (int q = 0; q < MAXE; ++q) z[q] = fma(-p, v[q], z[q]);
+            }
+            double gg = 0.0, g2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < MAXE; ++q) {
+                const int c = l + GL * q;
+                if (c < n) { gg = fma(z[q], sgp[c], gg); if (v2) g2 = fma(z[q], v2[c], g2); sV[j * n + c] = z[q]; }
+            }
+            gg += dpp_f64z<0xB1>(gg);
+            gg += dpp_f64z<0x4E>(gg);
+            gg += dpp_f64z<0x141>(gg);
+            if (GL == 16) gg += dpp_f64z<0x140>(gg);
+            if (l == 0) sgt[j] = gg;
+            if (v2) {
+                g2 += dpp_f64z<0xB1>(g2);
+                g2 += dpp_f64z<0x4E>(g2);
+                g2 += dpp_f64z<0x141>(g2);
+                if (GL == 16) g2 += dpp_f64z<0x140>(g2);
+                if (l == 0) o2[j] = g2;
+            }
+        }
+    } else {
+        if (tid < n) { sgt[tid] = sgp[tid]; if (v2) o2[tid] = v2[tid]; }
+    }
+    __syncthreads();
+    return noeig;
+
 }
 
 template <int CH>
 __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ UpdateCoef s_coef;
-    __shared__ int s_fail, s_flag;
     const int n = a.n, nn = n * n, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     // ---- persistent part
     double *sx = sm, *sbg = sx + n, *sgp = sbg + n, *sD = sgp + n, *sE = sD + n, *sTAU = sE + n, *sWT = sTAU + n, *sW = sWT + n, *sgt = sW + n,
            *scf = sgt + n, *sQ = scf + n, *sW6 = sQ + 6 * n, *sM6 = sW6 + 6 * n;
-    int *sperm = (int *)(sM6 + 36), *sbs = sperm + n, *sbe = sbs + n, *seinfo = sbe + n;
+    int *sperm = (int *)(sM6 + 36 + 2 * n), *sbs = sperm + n, *sbe = sbs + n, *seinfo = sbe + n;      // (2 n doubles in front: the P-RFO kernel's overlaps and TS vector)
     double *R1 = sm + ((small_r0_doubles(n) + 1) & ~(size_t)1);
     // ---- phase part, phases A .. C: the matrix, then the vectors of the update (or the tridiagonalisation's tables)
     double *M = R1, *aux = R1 + nn;
@@ -214,10 +448,9 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
         if (do_upd) { sg[i] = a.g[bn + i]; spx[i] = a.px[bn + i]; spg[i] = a.pg[bn + i]; }
         if (a.gamma) sW6[i] = a.tau[(size_t)(a.tau_first + b) * n + i];      // (the tangent borrows W's space until phase B)
     }
-    if (tid == 0) { s_fail = 0; s_flag = 0; }
     lds_barrier();
     if (wid == 15) small_trrot(n, sx, sQ, lane);
-    else if (wid == 14) small_projgrad(n, sx, sbg, sgp, lane);
+    else if (wid == 14) small_projgrad<0>(n, sx, sbg, sgp, lane);
     else {
         const double *H = a.Hin + bnn;
         if (a.gamma) {
@@ -317,208 +550,12 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
     }
     SM_STAMP();
     // ================= B. A = sym(H + bias), projected
-    {
-        const double *B = a.Bias ? a.Bias + bnn : nullptr;
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const int e = tid + 1024 * k;
-            if (e < nn) {
-                const int i = e / n, j = e - i * n;
-                double v = M[e], vt = M[j * n + i];
-                if (B) { v += B[e]; vt += B[j * n + i]; }
-                r1[k] = 0.5 * (v + vt);
-            }
-        }
-        lds_barrier();
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) { const int e = tid + 1024 * k; if (e < nn) M[e] = r1[k]; }
-        lds_barrier();
-        // W = A Q^T (A is bitwise symmetric: column reads, conflict-free)
-        if (tid < 6 * n) {
-            const int k = tid / n, i = tid - k * n;
-            double acc = 0.0;
-            for (int j = 0; j < n; ++j) acc += M[j * n + i] * sQ[k * n + j];
-            sW6[i * 6 + k] = acc;
-        }
-        lds_barrier();
-        if (tid < 36) {
-            const int k = tid / 6, l = tid - 6 * k;
-            double acc = 0.0;
-            for (int i = 0; i < n; ++i) acc += sQ[k * n + i] * sW6[i * 6 + l];
-            sM6[tid] = acc;
-        }
-        lds_barrier();
-        double wn = 0.0;
-        if (tid < 6 * n) {
-            const int l = tid / n, i = tid - l * n;
-            double t = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) t += sQ[k * n + i] * 0.5 * (sM6[k * 6 + l] + sM6[l * 6 + k]);
-            wn = sW6[i * 6 + l] - 0.5 * t;
-        }
-        lds_barrier();
-        if (tid < 6 * n) { const int l = tid / n, i = tid - l * n; sW6[i * 6 + l] = wn; }
-        lds_barrier();
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const int e = tid + 1024 * k;
-            if (e < nn) {
-                const int i = e / n, j = e - i * n;
-                double t = 0.0;
-#pragma unroll
-                for (int q = 0; q < 6; ++q) t += sQ[q * n + i] * sW6[j * 6 + q] + sW6[i * 6 + q] * sQ[q * n + j];
-                M[e] -= t;
-            }
-        }
-        lds_barrier();
-    }
+    small_sym_project(n, M, a.Bias ? a.Bias + bnn : nullptr, sQ, sW6, sM6, true);
     SM_STAMP();
-    // ================= C. tridiagonal form (reflectors stay in M, dsytrd layout: row k, columns k + 2 ..)
-    tri_tail_body<CH, 16>(n, -1, 0, M, sD, sE, sTAU, nullptr, aux);
-    __syncthreads();
-    {
-        double *Ag = a.A + bnn;                                // the divide and conquer needs the LDS: the reflectors wait in global memory
-        for (int e = tid; e < nn; e += 1024) Ag[e] = M[e];
-    }
-    SM_STAMP();
-    // ================= D. eigen-decomposition of the tridiagonal form
-    double *Zt = a.Zt + bnn;
-    {
-        int bad = 0;
-        for (int i = tid; i < n; i += 1024) if (!isfinite(sD[i]) || (i < n - 1 && !isfinite(sE[i]))) bad = 1;
-        bad = __syncthreads_or(bad);
-        if (tid == 0) s_flag = bad;
-        if (!bad) {
-            // splitting (the criterion of k_tri_bisect)
-            double en = 0.0;
-            if (tid < n - 1) { en = sE[tid]; if (fabs(en) <= 32.0 * SM_EPS * (fabs(sD[tid]) + fabs(sD[tid + 1])) || fabs(en) < SM_TINY) en = 0.0; }
-            __syncthreads();
-            if (tid < n) sE[tid] = en;
-            __syncthreads();
-            if (tid < n) {
-                int s = tid; while (s > 0 && sE[s - 1] != 0.0) --s;
-                int t = tid + 1; while (t < n && sE[t - 1] != 0.0) ++t;
-                sbs[tid] = s; sbe[tid] = t;
-            }
-            __syncthreads();
-            // blocks of at most SMALL_QL rows: one wave each, side by side (k_tri_ql32)
-            {
-                double *Zs = R1 + (size_t)wid * 32 * SMALL_QL;
-                int q = 0;
-                for (int s = 0; s < n; ++q) {
-                    const int t = sbe[s], m = t - s;
-                    if (m <= SMALL_QL && (q & 15) == wid) {
-                        if (m == 1) {
-                            if (lane == 0) sWT[s] = sD[s];
-                            for (int i = lane; i < n; i += WAVE) Zt[(size_t)s * n + i] = (i == s) ? 1.0 : 0.0;
-                        } else {
-                            double d = (lane < m) ? sD[s + lane] : 0.0, e = (lane < m - 1) ? sE[s + lane] : 0.0;
-                            const double nrm = wave_max(fmax(fabs(d), fabs(e)));
-                            const double sc = (nrm > 0.0) ? nrm : 1.0;
-                            d /= sc; e /= sc;
-                            for (int c = 0; c < m; ++c) Zs[c * 32 + (lane & 31)] = ((lane & 31) == c) ? 1.0 : 0.0;
-                            wave_sync_lds();
-                            const bool ok = ql_block32(m, d, e, Zs, lane);
-                            wave_sync_lds();
-                            if (!ok && lane == 0) atomicAdd(&s_fail, 1);
-                            if (lane < m) sWT[s + lane] = d * sc;
-                            for (int c = 0; c < m; ++c) {
-                                double *z = Zt + (size_t)(s + c) * n;
-                                for (int i = lane; i < n; i += WAVE) z[i] = (i >= s && i < t) ? Zs[c * 32 + (i - s)] : 0.0;
-                            }
-                            wave_sync_lds();
-                        }
-                    }
-                    s = t;
-                }
-            }
-            __syncthreads();
-            // larger blocks: the whole workgroup, one block after the other
-            for (int s = 0; s < n;) {
-                const int t = sbe[s], m = t - s;
-                if (m > SMALL_QL) { dc_block_body(n, s, m, b, sD + s, sE + s, sWT, Zt, &s_fail, R1, 0); __syncthreads(); }
-                s = t;
-            }
-        }
-    }
-    __syncthreads();
-    SM_STAMP();
-    // ================= E. ascending order, status
-    const int bad = s_flag;
-    {
-        int nf = 0;
-        if (!bad) for (int i = tid; i < n; i += 1024) if (!isfinite(sWT[i])) nf = 1;
-        nf = __syncthreads_or(nf);
-        if (tid < n) {
-            if (bad || nf) { sW[tid] = NAN; sperm[tid] = tid; }
-            else {
-                const double ki = sWT[tid];
-                int rank = 0;
-                for (int j = 0; j < tid; ++j) rank += sWT[j] <= ki;
-                for (int j = tid + 1; j < n; ++j) rank += sWT[j] < ki;
-                sW[rank] = ki; sperm[rank] = tid;
-            }
-        }
-        if (tid == 0) {
-            const int word = (bad || nf) ? 1 : (s_fail ? 4 : 0);
-            seinfo[0] = 0; seinfo[1] = word;
-            a.einfo[2 * b] = 0; a.einfo[2 * b + 1] = word;
-            if (a.sticky && (word & 12)) atomicOr(a.sticky, word & 12);
-            s_flag = (bad || nf) ? 1 : 0;
-        }
-    }
-    __syncthreads();
-    const int noeig = s_flag;                                 // non-finite eigen-system: identity fallback (rsirfo.py:365-372)
-    SM_STAMP();
-    // ================= F. V = Q Z, g~ = V^T g_proj
-    double *MR = R1, *sV = R1 + nn;
-    if (!noeig) {
-        const double *Ag = a.A + bnn;
-        for (int e = tid; e < nn; e += 1024) MR[e] = Ag[e];
-        __syncthreads();
-        // GL lanes per eigenvector (16 for n <= 64, 8 above: every vector of the matrix is in flight in ONE pass), a lane holds components
-        // l, l + GL, ...; a reflector then costs one LDS row read shared by all groups and a reduction over GL lanes only
-        constexpr int GL = (CH == 1) ? 16 : 8, MAXE = (CH == 1) ? 4 : 9, VPW = 64 / GL;
-        const int l = lane & (GL - 1);
-        const int j = wid * VPW + lane / GL;
-        if (j < n) {
-            double z[MAXE];
-#pragma unroll
-            for (int q = 0; q < MAXE; ++q) { const int c = l + GL * q; z[q] = (c < n) ? Zt[(size_t)j * n + c] : 0.0; }
-            for (int k = n - 3; k >= 0; --k) {
-                const double tau = sTAU[k];
-                if (tau == 0.0) continue;
-                double v[MAXE], p = 0.0;
-#pragma unroll
-                for (int q = 0; q < MAXE; ++q) {
-                    const int c = l + GL * q;
-                    v[q] = (c == k + 1) ? 1.0 : ((c > k + 1 && c < n) ? MR[k * n + c] : 0.0);
-                    p = fma(v[q], z[q], p);
-                }
-                p += dpp_f64z<0xB1>(p);
-                p += dpp_f64z<0x4E>(p);
-                p += dpp_f64z<0x141>(p);
-                if (GL == 16) p += dpp_f64z<0x140>(p);
-                p *= tau;
-#pragma unroll
-                for (int q = 0; q < MAXE; ++q) z[q] = fma(-p, v[q], z[q]);
-            }
-            double gg = 0.0;
-#pragma unroll
-            for (int q = 0; q < MAXE; ++q) {
-                const int c = l + GL * q;
-                if (c < n) { gg = fma(z[q], sgp[c], gg); sV[j * n + c] = z[q]; }
-            }
-            gg += dpp_f64z<0xB1>(gg);
-            gg += dpp_f64z<0x4E>(gg);
-            gg += dpp_f64z<0x141>(gg);
-            if (GL == 16) gg += dpp_f64z<0x140>(gg);
-            if (l == 0) sgt[j] = gg;
-        }
-    } else {
-        if (tid < n) sgt[tid] = sgp[tid];
-    }
-    __syncthreads();
+    // ================= C .. F. eigen-decomposition, g~ = V^T g_proj
+    const int noeig = small_eigen<CH>(n, b, M, aux, R1, sD, sE, sTAU, sWT, sW, sperm, sbs, sbe, seinfo, a.A + bnn, a.Zt + bnn, a.einfo + 2 * b, a.sticky, sgp, sgt,
+                                      nullptr, nullptr);
+    double *sV = R1 + nn;
     SM_STAMP();
     // ================= G. scalar stage (wave 0; its barriers are wave-level)
     if (wid == 0)
@@ -550,10 +587,201 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
         if (tid == 0) __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (a.dbg && tid == 0 && b == 0)
-        printf("[small] n=%d: A update %.1f, B project %.1f, C tridiag %.1f, D eigen %.1f, E sort %.1f, F backtransform %.1f, G scalar %.1f, H step %.1f us\n", n,
-               (stamp[1] - stamp[0]) * 0.01, (stamp[2] - stamp[1]) * 0.01, (stamp[3] - stamp[2]) * 0.01, (stamp[4] - stamp[3]) * 0.01, (stamp[5] - stamp[4]) * 0.01,
-               (stamp[6] - stamp[5]) * 0.01, (stamp[7] - stamp[6]) * 0.01, (stamp[8] - stamp[7]) * 0.01);
+        printf("[small] n=%d: A update %.1f, B project %.1f, C-F eigen %.1f, G scalar %.1f, H step %.1f us\n", n,
+               (stamp[1] - stamp[0]) * 0.01, (stamp[2] - stamp[1]) * 0.01, (stamp[3] - stamp[2]) * 0.01, (stamp[4] - stamp[3]) * 0.01, (stamp[5] - stamp[4]) * 0.01);
 #undef SM_STAMP
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// EnhancedRSPRFO.run (multioptpy/Optimizer/rsprfo.py:713-886) for one small geometry, same construction:
+//   1  previous step (:753-760, 908-962): reduction ratio with the TR/rot-projected sym(H + bias), trust radius, rejection counter
+//   2  checked quasi-Newton update (:765-767, 1190-1260): candidate sym(H + dH); its infinity norm bounds max |eig|, so the spectrum
+//      test (> 1e6) can only fail when that bound does -- the kernel then stops with status 2 and the caller repeats the call through the
+//      general path, which computes the spectrum
+//   3  projected gradient (variant with the rank test, :245-281) and its norm
+//   4  eigh(sym(H + bias)), NOT projected (:780-783); g~ = V^T g_proj; overlaps V^T ts
+//   5  scalar stage by wave 0 (prfo_body.hpp: shifting, mode following, micro cycles), step, tracked TS vector
+struct SmallPrfoArgs {
+    int n, has_prev_step, do_update, have_ts, dbg;
+    double B_e, pre_move_norm;
+    const mopt_rsprfo_params *params; mopt_rsprfo_state *state;
+    const double *x, *bg, *px, *pg, *prevg, *prevs, *ts, *Hin, *Bias;
+    double *Hout, *step, *tsout;
+    int *flags;                    // [0] updated, [1] Vt row of the tracked TS mode (-1: none), [2] eigen-solver status word, [3] status (0 done, 2 see above)
+    double *A, *Zt;
+    UpdateCoef *coef;
+    int *sticky;
+    unsigned long long *done;
+};
+
+template <int CH>
+__global__ void __launch_bounds__(1024) k_small_rsprfo(SmallPrfoArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ UpdateCoef s_coef;
+    __shared__ mopt_rsprfo_state s_st;
+    __shared__ double s_gn, s_red[16];
+    __shared__ int s_tsrow, s_einfo_g[2];
+    const int n = a.n, nn = n * n, tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *sx = sm, *sbg = sx + n, *sgp = sbg + n, *sD = sgp + n, *sE = sD + n, *sTAU = sE + n, *sWT = sTAU + n, *sW = sWT + n, *sgt = sW + n,
+           *scf = sgt + n, *sQ = scf + n, *sW6 = sQ + 6 * n, *sM6 = sW6 + 6 * n, *sov = sM6 + 36, *sts = sov + n;
+    int *sperm = (int *)(sts + n), *sbs = sperm + n, *sbe = sbs + n, *seinfo = sbe + n;
+    double *R1 = sm + ((small_r0_doubles(n) + 1) & ~(size_t)1);
+    double *M = R1, *M2 = R1 + nn, *aux = R1 + 2 * nn;
+    double *spx = aux, *spg = spx + n, *ss = spg + n, *sy = ss + n, *su = sy + n, *shy = su + n, *syd = shy + n, *sAv = syd + n, *sprevg = sAv + n, *sprevs = sprevg + n;
+    const int rule = a.params[0].rule;
+    const bool flow = rule == MOPT_RULE_FLOWCHART;
+    constexpr int EPT = 6;
+
+    for (int i = tid; i < n; i += 1024) {
+        sx[i] = a.x[i]; sbg[i] = a.bg[i];
+        if (a.do_update) { spx[i] = a.px[i]; spg[i] = a.pg[i]; }
+        if (a.has_prev_step) { sprevg[i] = a.prevg[i]; sprevs[i] = a.prevs[i]; }
+        sts[i] = a.have_ts ? a.ts[i] : 0.0;
+    }
+    if (tid == 0) { s_st = a.state[0]; s_tsrow = -1; }
+    lds_barrier();
+    if (wid == 15) { if (a.has_prev_step) small_trrot(n, sx, sQ, lane); }
+    else if (wid == 14) { const double gn = small_projgrad<1>(n, sx, sbg, sgp, lane); if (lane == 0) s_gn = gn; }
+    else {
+        for (int e = tid; e < nn; e += 896) M[e] = a.Hin[e];
+        if (a.do_update) for (int i = tid; i < n; i += 896) { ss[i] = sx[i] - spx[i]; sy[i] = sbg[i] - spg[i]; }
+    }
+    lds_barrier();
+    int updated = 0;
+    // ================= 1. previous step
+    if (a.has_prev_step) {
+        for (int e = tid; e < nn; e += 1024) M2[e] = M[e];
+        lds_barrier();
+        small_sym_project(n, M2, a.Bias, sQ, sW6, sM6, true);
+        const int grp = tid >> 4, l = tid & 15;
+        for (int r = grp; r < n; r += 64) {
+            double a1 = 0.0;
+            for (int j = l; j < n; j += 16) a1 += M2[r * n + j] * sprevs[j];
+            a1 = row16_sum(a1);
+            if (l == 0) su[r] = a1;
+        }
+        lds_barrier();
+        if (wid == 0) {
+            double v[3] = {0, 0, 0};
+            for (int i = lane; i < n; i += WAVE) { v[0] += sprevg[i] * sprevs[i]; v[1] += sprevs[i] * su[i]; v[2] += sprevs[i] * sprevs[i]; }
+            const double gs = wave_sum(v[0]), sHs = wave_sum(v[1]), sps = wave_sum(v[2]);
+            if (lane == 0) {
+                const mopt_rsprfo_params p = a.params[0];
+                mopt_rsprfo_state st = s_st;
+                prfo_prev_logic(p, st, gs, sHs, sps, a.B_e, a.pre_move_norm);
+                s_st = st;
+            }
+        }
+        lds_barrier();
+    }
+    // ================= 2. checked update with y = B_g - pre_B_g
+    if (a.do_update) {
+        const int grp = tid >> 4, l = tid & 15;
+        for (int r = grp; r < n; r += 64) {
+            double a1 = 0.0, a2 = 0.0;
+            for (int j = l; j < n; j += 16) { const double h = M[r * n + j]; a1 += h * ss[j]; if (flow) a2 += h * sy[j]; }
+            a1 = row16_sum(a1);
+            if (flow) a2 = row16_sum(a2);
+            if (l == 0) { su[r] = a1; if (flow) shy[r] = a2; }
+        }
+        lds_barrier();
+        if (wid == 0) {
+            double v[4] = {0, 0, 0, 0};
+            for (int i = lane; i < n; i += WAVE) { const double si = ss[i], yi = sy[i], ui = su[i]; v[0] += si * si; v[1] += si * yi; v[2] += yi * yi; v[3] += si * ui; }
+            UpdateDots d;
+            d.ss = wave_sum(v[0]); d.sy = wave_sum(v[1]); d.yy = wave_sum(v[2]); d.su = wave_sum(v[3]);
+            double theta = 1.0;
+            bool damp = false;
+            if (rule_is_dd(rule)) { damp = d.sy < 0.2 * d.ss; theta = dd_theta(d.ss, d.sy, rule_is_block(rule) ? 1e-12 : 1e-10); }
+            double w[5] = {0, 0, 0, 0, 0};
+            for (int i = lane; i < n; i += WAVE) {
+                const double si = ss[i], yi = sy[i], ui = su[i];
+                const double ydi = damp ? theta * yi + (1.0 - theta) * si : yi;
+                const double ai = ydi - ui;
+                syd[i] = ydi; sAv[i] = ai;
+                w[0] += si * ydi; w[1] += ai * ai; w[2] += ai * si;
+                if (flow) { const double zi = yi - shy[i]; w[3] += zi * zi; w[4] += zi * si; }
+            }
+            d.syd = wave_sum(w[0]); d.AA = wave_sum(w[1]); d.As = wave_sum(w[2]); d.zz = wave_sum(w[3]); d.zs = wave_sum(w[4]);
+            if (lane == 0) { const UpdateCoef c = update_coefficients(rule, d, /*require_positive_sy=*/false); s_coef = c; a.coef[0] = c; }
+        }
+        lds_barrier();
+        const UpdateCoef c = s_coef;
+        if (c.applied) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                const int e = tid + 1024 * k;
+                if (e < nn) {
+                    const int i = e / n, j = e - i * n;
+                    const double hij = M[e], hji = M[j * n + i];
+                    const double yi = syd[i], ui = su[i], ai = sAv[i], si = ss[i], yj = syd[j], uj = su[j], aj = sAv[j], sj = ss[j];
+                    double dlt = sm_mul(c.c_yy, sm_mul(yi, yj));
+                    dlt = dlt + sm_mul(c.c_uu, sm_mul(ui, uj));
+                    dlt = dlt + sm_mul(c.c_AA, sm_mul(ai, aj));
+                    dlt = dlt + sm_mul(c.c_As, sm_mul(ai, sj) + sm_mul(si, aj));
+                    dlt = dlt + sm_mul(c.c_ss, sm_mul(si, sj));
+                    M2[e] = 0.5 * ((hij + dlt) + (hji + dlt));
+                }
+            }
+            lds_barrier();
+            // ||candidate||_inf >= max |eig| (k_jac_sigma's bound)
+            double rs = 0.0;
+            if (tid < n) for (int j = 0; j < n; ++j) rs += fabs(M2[j * n + tid]);
+            rs = wave_max(rs);
+            if (lane == 0) s_red[wid] = rs;
+            lds_barrier();
+            double mx = 0.0;
+            for (int w_ = 0; w_ < 16; ++w_) mx = fmax(mx, s_red[w_]);
+            const bool need_spectrum = (mx > 0.0 && isfinite(mx)) && !(mx <= 1e6);
+            if (need_spectrum) {
+                if (tid == 0) { a.flags[3] = 2; __threadfence_system(); if (a.done) __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
+                return;
+            }
+            for (int e = tid; e < nn; e += 1024) { const double h = M2[e]; M[e] = h; a.Hout[e] = h; }
+            updated = 1;
+            lds_barrier();
+        }
+    }
+    // ================= 3./4. A = sym(H + bias), eigen-decomposition, g~, overlaps
+    small_sym_project(n, M, a.Bias, sQ, sW6, sM6, false);
+    const int noeig = small_eigen<CH>(n, 0, M, aux, R1, sD, sE, sTAU, sWT, sW, sperm, sbs, sbe, seinfo, a.A, a.Zt, s_einfo_g, a.sticky, sgp, sgt,
+                                      a.have_ts ? sts : nullptr, sov);
+    double *sV = R1 + nn;
+    // ================= 5. scalar stage
+    if (wid == 0) {
+        if (lane == 0) s_st.gradient_norm = s_gn;
+        wave_sync_lds();
+        prfo_scalar_body<true>(n, a.params, &s_st, sW, sperm, seinfo, sgt, sov, a.have_ts, scf, &s_tsrow, R1 + 2 * nn);
+    }
+    lds_barrier();
+    if (tid < n) {
+        double out;
+        if (noeig) out = -scf[tid];
+        else {
+            double t0 = 0.0, t1 = 0.0;
+            int i = 0;
+            for (; i + 1 < n; i += 2) {
+                const double c0 = scf[i], c1 = scf[i + 1];
+                t0 = fma(c0, c0 != 0.0 ? sV[i * n + tid] : 0.0, t0);
+                t1 = fma(c1, c1 != 0.0 ? sV[(i + 1) * n + tid] : 0.0, t1);
+            }
+            if (i < n) { const double c0 = scf[i]; t0 = fma(c0, c0 != 0.0 ? sV[i * n + tid] : 0.0, t0); }
+            out = -(t0 + t1);
+        }
+        a.step[tid] = out;
+        const int r = s_tsrow;
+        if (a.tsout && r >= 0) a.tsout[tid] = noeig ? (tid == r ? 1.0 : 0.0) : sV[r * n + tid];
+    }
+    if (tid == 0) {
+        a.state[0] = s_st;
+        a.flags[0] = updated; a.flags[1] = s_tsrow; a.flags[2] = seinfo[1]; a.flags[3] = 0;
+    }
+    if (a.done) {
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 }  // namespace mopt
@@ -621,4 +849,43 @@ int mopt_launch_small_rsirfo(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bo
     io.rules = wk.rules; io.do_update = fb ? nullptr : wk.do_update;      // (band, fused form: every image updates, or none)
     io.Hin = wk.H; io.Bias = wk.Bias; io.Hsym = d_Hsym; io.Hinpl = d_Hinpl; io.step = wk.step; io.done = nullptr;
     return mopt_launch_small_rsirfo_io(ctx, wk, n, batch, any_update, any_flowchart, io);
+}
+
+// EnhancedRSPRFO.run for one small geometry (k_small_rsprfo).  Every pointer of `io` is device-visible; wk supplies A, Vt, coef, sticky.
+int mopt_launch_small_rsprfo(mopt_ctx *ctx, RsirfoWork &wk, const SmallPrfoIO &io) {
+    using namespace mopt;
+    const int n = io.n;
+    if (!mopt_small_eligible(n)) { ctx->err = "mopt_launch_small_rsprfo: n out of range"; return MOPT_E_ARG; }
+    SmallPrfoArgs a;
+    a.n = n; a.has_prev_step = io.has_prev_step; a.do_update = io.do_update; a.have_ts = io.have_ts; a.dbg = 0;
+    a.B_e = io.B_e; a.pre_move_norm = io.pre_move_norm;
+    a.params = io.params; a.state = io.state;
+    a.x = io.x; a.bg = io.bg; a.px = io.px; a.pg = io.pg; a.prevg = io.prevg; a.prevs = io.prevs; a.ts = io.ts; a.Hin = io.Hin; a.Bias = io.Bias;
+    a.Hout = io.Hout; a.step = io.step; a.tsout = io.tsout; a.flags = io.flags;
+    a.A = wk.A; a.Zt = wk.Vt; a.coef = wk.coef; a.sticky = wk.sticky; a.done = io.done;
+    const size_t nn = (size_t)n * n;
+    const size_t pa = 2 * nn + small_aux_doubles(n);
+    const size_t pql = (size_t)16 * 32 * SMALL_QL;
+    const size_t dsmall = (size_t)10 * n * 8 + (size_t)n * sizeof(DcRot) + 8 * 8 + (size_t)8 * n * 4 + 64;
+    const size_t dtabs = (size_t)3 * nn * 8, dleaf = (nn + (size_t)16 * 32 * DCB_LEAF) * 8;
+    const size_t pdc = (dsmall + (dtabs > dleaf ? dtabs : dleaf) + 7) / 8;
+    const size_t pf = 2 * nn + (size_t)7 * n + (size_t)2 * n + 4;
+    size_t ph = pa;
+    if (pql > ph) ph = pql;
+    if (pdc > ph) ph = pdc;
+    if (pf > ph) ph = pf;
+    const size_t lds = (((small_r0_doubles(n) + 1) & ~(size_t)1) + ph + 2) * 8;
+    if (lds > (size_t)ctx->lds_limit - 4096) { ctx->err = "k_small_rsprfo: LDS budget exceeded"; return MOPT_E_ARG; }
+    const void *fn = n <= 64 ? (const void *)k_small_rsprfo<1> : (const void *)k_small_rsprfo<2>;
+    static bool attr_set[64][2] = {};
+    const int dv = ctx->device & 63, vi = n <= 64 ? 0 : 1;
+    if (!attr_set[dv][vi]) {
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 2048));
+        attr_set[dv][vi] = true;
+    }
+    mopt_scope sc(ctx, "small_step", 1);
+    void *args[] = {&a};
+    MOPT_HIP_TRY(ctx, hipLaunchKernel(fn, dim3(1), dim3(1024), args, lds, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    return MOPT_OK;
 }

@@ -535,6 +535,12 @@ static int ws_get(mopt_ctx *ctx, int n, int batch, bool own_h, bool bias, bool i
     return MOPT_OK;
 }
 
+// (for k_prfo.hip: the cached workspace of a single small geometry)
+int mopt_ws_get_small(mopt_ctx *ctx, int n, RsirfoWork **wk_out) {
+    void *io = nullptr;
+    return ws_get(ctx, n, 1, true, false, false, 256, wk_out, &io);
+}
+
 // Small geometries (k_small.hip): the kernel reads its inputs from, and writes its results to, one pinned host span it can address, and
 // the host waits for the kernel's completion counter in that span instead of for the stream -- no copy command and no stream wake-up
 // on the path (five copies and the synchronisation were 40 us of a 195 us call at n = 21).  Span: [inputs | states | step | H | bias |

@@ -81,6 +81,18 @@ struct SmallStepIO {
     int tau_first = 0;
 };
 int mopt_launch_small_rsirfo_io(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch, bool any_update, bool any_flowchart, const SmallStepIO &io);
+// EnhancedRSPRFO.run for one small geometry in one launch (k_small_rsprfo); flags: [0] Hessian updated, [1] Vt row of the tracked TS mode or -1,
+// [2] eigen-solver status word, [3] 0 done / 2 "the candidate's norm bound exceeds 1e6: repeat through the general path".
+struct SmallPrfoIO {
+    int n, has_prev_step, do_update, have_ts;
+    double B_e, pre_move_norm;
+    const mopt_rsprfo_params *params; mopt_rsprfo_state *state;
+    const double *x, *bg, *px, *pg, *prevg, *prevs, *ts, *Hin, *Bias;
+    double *Hout, *step, *tsout;
+    int *flags;
+    unsigned long long *done;
+};
+int mopt_launch_small_rsprfo(mopt_ctx *ctx, RsirfoWork &wk, const SmallPrfoIO &io);
 
 // Images whose eigen-solve reported a hand-off time-out of the persistent tridiagonalisation (einfo bit 8; k_rfo_scalar leaves their
 // state untouched): A is formed again from the (already updated) Hessian and the image is solved with one launch per Householder

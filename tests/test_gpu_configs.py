@@ -774,3 +774,107 @@ def test_rsirfo_nan_hessian_identity_fallback(N):
     finally:
         orf.np.linalg.eigh = real_eigh
     assert np.abs(dev - ref).max() < 1e-8, np.abs(dev - ref).max()
+
+
+@pytest.mark.parametrize("natoms,method,order", [(3, "rsirfo_bfgs", 0), (8, "rsirfo_fsb", 1), (21, "rsirfo_bofill", 1), (22, "rsirfo_flowchart", 0),
+                                                 (24, "rsirfo_bfgs", 0), (24, "rsirfo_msp", 2)])
+def test_small_step_kernel_vs_oracle(natoms, method, order):
+    """The one-workgroup step kernel (k_small.hip: 9 <= n <= 72) at its edges -- three atoms, 64 < n <= 72 (second register chunk,
+    eight lanes per eigenvector), the flowchart rule (needs H y), saddle orders 0 .. 2 -- against the oracle's RSIRFO on the same inputs."""
+    import contextlib
+    import io
+    from multioptpy_amd.Optimizer.rsirfo import RSIRFO
+    from oracle.rsirfo import RSIRFO as Oracle
+    n = 3 * natoms
+    x0 = cases.cluster(natoms, jitter=0.2) * 0.97
+    H0 = cases.lj(x0, hessian=True)[2]
+    a = RSIRFO(method=method, saddle_order=order, element_list=["Ar"] * natoms)
+    b = Oracle(method=method, saddle_order=order, element_list=["Ar"] * natoms)
+    for o in (a, b):
+        o.set_hessian(H0.copy())
+        o.set_bias_hessian(np.zeros((n, n)))
+    xs, px, pg, pe = x0.copy(), [], [], 0.0
+    worst = 0.0
+    for it in range(8):
+        e, g = cases.lj(xs)[:2]
+        ma = a.run(xs.reshape(-1, 1), g.reshape(-1, 1), pg, px, e, pe, [], [], g.reshape(-1, 1), pg)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mb = b.run(xs.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), pg, px, e, pe, [], [], g.reshape(-1, 1).copy(), pg)
+        err = np.abs(np.asarray(ma) - np.asarray(mb)).max()
+        worst = max(worst, err)
+        assert err < 1e-9, (it, err)
+        assert np.abs(np.asarray(a.hessian) - np.asarray(b.hessian)).max() < 1e-10, it
+        px, pg, pe = xs.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), e
+        step = np.asarray(ma).reshape(natoms, 3)
+        xs = xs - step * min(1.0, 0.1 / max(np.linalg.norm(step), 1e-12))
+    print(f"N = {natoms} {method} order {order}: worst deviation {worst:.2e}")
+
+
+def test_small_step_kernel_matches_general_pipeline():
+    """The same RSIRFO and EnhancedRSPRFO trajectories with the one-workgroup kernels and with the general pipeline (MOPT_SMALL=0): equal
+    to rounding (near a minimum: one shifted mode, no surplus negative ones whose degenerate images would make the mode choice a matter of
+    rounding, see test_rsprfo_surplus_negative_modes_vs_oracle)."""
+    import os
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests', 'golden')); "
+            "import numpy as np, cases; from multioptpy_amd.Optimizer.rsirfo import RSIRFO; from multioptpy_amd.Optimizer.rsprfo import EnhancedRSPRFO\n"
+            "out = []\n"
+            "for N, cls, meth in ((7, RSIRFO, 'rsirfo_fsb'), (14, RSIRFO, 'rsirfo_fsb'), (22, RSIRFO, 'rsirfo_fsb'), (7, EnhancedRSPRFO, 'rsprfo_bofill'), (24, EnhancedRSPRFO, 'rsprfo_fsb')):\n"
+            "    x = cases.cluster(N, jitter=0.05) * 0.99; n = 3 * N\n"
+            "    o = cls(method=meth, saddle_order=1, element_list=['Ar'] * N); o.set_hessian(cases.lj(x, hessian=True)[2].copy()); o.set_bias_hessian(np.zeros((n, n)))\n"
+            "    px = pg = []\n"
+            "    for it in range(6):\n"
+            "        e, g = cases.lj(x)[:2]; mv = o.run(x.reshape(-1, 1), g.reshape(-1, 1), pg, px, e, 0.0, [], [], g.reshape(-1, 1), pg)\n"
+            "        px, pg = x.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(); st = np.asarray(mv).reshape(N, 3); x = x - st * min(1.0, 0.1 / max(np.linalg.norm(st), 1e-12)); out.append(np.asarray(mv).ravel())\n"
+            "np.save(sys.argv[1], np.concatenate(out))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for small in ("1", "0"):
+        f = os.path.join("/tmp", f"mopt_small_{small}_{os.getpid()}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, MOPT_SMALL=small), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+        os.remove(f)
+    d = np.abs(outs[0] - outs[1]).max()
+    print("one-workgroup kernels vs general pipeline, move vectors of 30 steps:", d)
+    assert d < 1e-10
+
+
+@pytest.mark.parametrize("natoms,method,order", [(3, "rsprfo_bofill", 1), (8, "rsprfo_flowchart", 1), (24, "rsprfo_fsb", 1), (24, "rsprfo_bofill", 2)])
+def test_small_prfo_kernel_vs_oracle(natoms, method, order):
+    """k_small_rsprfo at its edges (three atoms, 64 < n <= 72, the flowchart rule, saddle order 2) against the oracle's EnhancedRSPRFO on the
+    same inputs; stops where the oracle reports a basis-dependent mode choice."""
+    import contextlib
+    import io
+    from multioptpy_amd.Optimizer.rsprfo import EnhancedRSPRFO
+    from oracle.rsprfo import EnhancedRSPRFO as Oracle
+    n = 3 * natoms
+    x0 = cases.cluster(natoms, jitter=0.05) * 0.99
+    H0 = cases.lj(x0, hessian=True)[2]
+    a = EnhancedRSPRFO(method=method, saddle_order=order, element_list=["Ar"] * natoms)
+    b = Oracle(method=method, saddle_order=order, element_list=["Ar"] * natoms)
+    for o in (a, b):
+        o.set_hessian(H0.copy())
+        o.set_bias_hessian(np.zeros((n, n)))
+    xs, px, pg, pe = x0.copy(), [], [], 0.0
+    compared, worst = 0, 0.0
+    for it in range(8):
+        e, g = cases.lj(xs)[:2]
+        ma = a.run(xs.reshape(-1, 1), g.reshape(-1, 1), pg, px, e, pe, [], [], g.reshape(-1, 1), pg)
+        with contextlib.redirect_stdout(io.StringIO()):
+            mb = b.run(xs.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), pg, px, e, pe, [], [], g.reshape(-1, 1).copy(), pg)
+        if b.trace.get("basis_dependent", False):
+            break
+        err = np.abs(np.asarray(ma) - np.asarray(mb)).max()
+        worst = max(worst, err)
+        assert err < 1e-9, (it, err)
+        assert abs(a.trust_radius - b.trust_radius) < 1e-12, it
+        assert np.abs(np.asarray(a.hessian) - np.asarray(b.hessian)).max() < 1e-10, it
+        compared += 1
+        px, pg, pe = xs.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), e
+        step = np.asarray(ma).reshape(natoms, 3)
+        xs = xs - step * min(1.0, 0.1 / max(np.linalg.norm(step), 1e-12))
+    print(f"N = {natoms} {method} order {order}: {compared} steps compared, worst deviation {worst:.2e}")
+    # (saddle order 2 near a minimum: both lowest modes are shifted to min_negative_eigval -- a degenerate pair from the second step on)
+    assert compared >= (2 if order == 1 else 1)
