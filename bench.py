@@ -134,7 +134,8 @@ def cpu_baseline(traj, I, N, budget_s=25.0, hess0=None):
 
 
 FAMILIES = ("hess_update", "project", "eigh_init", "eigh_jacobi", "eigh_tridiag", "eigh_bisect", "eigh_invit", "eigh_backtrans",
-            "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post", "halo", "eigh_dc", "rfo_scalar", "eigh_small", "eigh_early", "apply_qt", "larft")
+            "eigh_final", "rfo", "neb_force", "neb_ayala", "neb_post", "halo", "eigh_dc", "rfo_scalar", "eigh_small", "eigh_early", "apply_qt", "larft",
+            "small_step")
 # algorithmic bytes per image-step of a family in units of n^2 (80 n^2 for the whole RSIRFO.run, of which the
 # eigen-solve's share is input read + eigenvector write; reduction route: the tridiagonalisation reads the matrix once (8 n^2)
 # and leaves the reflectors in its strict upper triangle (4 n^2); the back-transformation reads reflectors + eigenvectors and
@@ -143,9 +144,10 @@ SHARE_BYTES = {"eigh_jacobi": 16.0, "eigh_tridiag": 12.0, "eigh_backtrans": 20.0
                "project": 16.0, "rfo": 24.0}
 SHARE_FLOPS = {"eigh_tridiag": 4.0 / 3.0, "eigh_backtrans": 2.0}
 KERNEL_OF = {"eigh_jacobi": "k_jac_step", "eigh_tridiag": "k_tri_persist3", "eigh_backtrans": "k_tri_backtrans_mfma",
-             "eigh_invit": "k_tri_invit", "eigh_bisect": "k_tri_bisect"}
+             "eigh_invit": "k_tri_invit", "eigh_bisect": "k_tri_bisect", "small_step": "k_small_rsirfo"}
 # what the dominant kernel is actually bound by; the HBM and FP64 fractions are reported beside it
-BOUND_NOTE = {"eigh_tridiag": "latency (inter-workgroup hand-off chain of n-1 dependent Householder steps)",
+BOUND_NOTE = {"small_step": "latency (one workgroup per image runs the whole step: barrier-separated phases of a few us each, matrices in LDS)",
+              "eigh_tridiag": "latency (inter-workgroup hand-off chain of n-1 dependent Householder steps)",
               "eigh_invit": "latency (sequential inverse iteration inside eigenvalue clusters)",
               "eigh_bisect": "instruction issue (Sturm recurrences)"}
 

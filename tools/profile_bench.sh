@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS=${MOPT_PROFILE_ARGS:-"--steps 10 --warmup 2 --no-cpu-baseline"}
+ARGS=${MOPT_PROFILE_ARGS:-"--no-cpu-baseline"}      # the default bench command (20 steps, 3 warm-up): per-kernel averages comparable with its own line
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $ROOT/bench.py $ARGS > $OUT/bench_under_stats.json 2> $OUT/stats.err
 echo "stats pass done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $ROOT/bench.py $ARGS > $OUT/bench_under_fetch.json 2> $OUT/fetch.err
