@@ -202,6 +202,19 @@ int mopt_rsirfo_run(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *p
                     const double *geom, const double *B_g, const double *g, const double *pre_geom,
                     const double *pre_g, const double *B_e, double *step, double *H_inplace, double *H_sym);
 
+/* ---- MF_RSIRFO.run (multioptpy/Optimizer/mf_rsirfo.py:128-265) in two halves.  The mode follower (Optimizer/mode_following.py: overlaps with
+   its reference vectors, Hungarian / greedy matching, EMA update) works on the eigenvectors between the eigen-decomposition and the step, on the
+   host; everything else stays on the device between the two calls.
+     mopt_mf_rsirfo_begin   Hessian update (rsirfo.py:1316-1372), TR/rot projection, eigh (mf_rsirfo.py:148-171): W_out[n] ascending eigenvalues,
+                            V_out[n][n] row k = eigenvector k (the identity when the spectrum is not finite); H_inplace / H_sym as mopt_rsirfo_run.
+     mopt_mf_rsirfo_finish  trust radius with the curvature of the first target (:196-205), image function over `targets` (ascending positions, :207-218),
+                            RS step with the UNPROJECTED gradient B_g (:163), predicted change, state; step[n] = the value run() returns.
+   One geometry per call pair; finish must follow begin on the same context with the same n. */
+int mopt_mf_rsirfo_begin(mopt_ctx *ctx, int n, const mopt_rsirfo_params *params, const mopt_rsirfo_state *state, const double *hessian,
+                         const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom, const double *pre_g,
+                         double B_e, double *W_out, double *V_out, double *H_inplace, double *H_sym, int *hess_updated);
+int mopt_mf_rsirfo_finish(mopt_ctx *ctx, int n, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const int *targets, int ntargets, double *step);
+
 /* ---- EnhancedRSPRFO.run (multioptpy/Optimizer/rsprfo.py:713-886): P-RFO transition-state step ------------------ */
 
 typedef struct mopt_rsprfo_params {

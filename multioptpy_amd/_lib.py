@@ -54,6 +54,10 @@ def _proto(lib):
     lib.mopt_neb_force.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, C.c_int, C.c_int, DP, DP]
     lib.mopt_rsirfo_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),
                                     DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
+    if hasattr(lib, "mopt_mf_rsirfo_begin"):
+        lib.mopt_mf_rsirfo_begin.argtypes = [vp, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState), DP, DP, DP, DP, DP, DP, DP, C.c_double,
+                                             DP, DP, DP, DP, C.POINTER(C.c_int)]
+        lib.mopt_mf_rsirfo_finish.argtypes = [vp, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState), C.POINTER(C.c_int), C.c_int, DP]
     lib.mopt_rsprfo_run.argtypes = [vp, C.c_int, C.POINTER(_abi.RsprfoParams), C.POINTER(_abi.RsprfoState), DP, DP, DP, DP, DP, DP,
                                     C.c_double, DP, DP, C.c_double, DP, DP, DP, DP]
     if hasattr(lib, "mopt_band_create"):

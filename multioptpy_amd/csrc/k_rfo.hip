@@ -35,9 +35,9 @@ __global__ void __launch_bounds__(192) k_rfo_scalar(int n, const mopt_rsirfo_par
                                                    const int *__restrict__ perm, const int *__restrict__ einfo,
                                                    const double *__restrict__ gt_all_, const double *__restrict__ Bg,
                                                    const double *__restrict__ Be, const UpdateCoef *__restrict__ coef,
-                                                   double *__restrict__ coef_out_, int dbg) {
+                                                   double *__restrict__ coef_out_, int dbg, const int *__restrict__ mf, int nmf) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    rfo_scalar_body<false>(n, (int)blockIdx.x, params, states, W, perm, einfo, gt_all_, Bg, Be, coef, coef_out_, dbg, sm);
+    rfo_scalar_body<false>(n, (int)blockIdx.x, params, states, W, perm, einfo, gt_all_, Bg, Be, coef, coef_out_, dbg, sm, mf, nmf);
 }
 
 // out[b][j] = - sum_i coef[b][i] Vt[b][i][j]     grid (ceil(n/64), batch), block 1024: 16 waves share the rows of a
@@ -79,12 +79,12 @@ __global__ void __launch_bounds__(1024) k_backtransform(int n, const double *__r
 
 int mopt_launch_rfo_scalar(mopt_ctx *ctx, hipStream_t st, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                            const double *d_W, const int *d_perm, const int *d_einfo, const double *d_gt_all, const double *d_Bg, const double *d_Be,
-                           const mopt::UpdateCoef *d_coef, double *d_coefout) {
+                           const mopt::UpdateCoef *d_coef, double *d_coefout, const int *d_mf, int nmf) {
     using namespace mopt;
     static const int dbg = getenv("MOPT_RFO_DBG") ? 1 : 0;
     const size_t lds = (size_t)15 * n * sizeof(double) + (size_t)3 * n * sizeof(int) + 16;
     if (lds > 48000) MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_rfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
-    hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(192), lds, st, n, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout, dbg);
+    hipLaunchKernelGGL(k_rfo_scalar, dim3(batch), dim3(192), lds, st, n, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout, dbg, d_mf, nmf);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }
@@ -92,11 +92,11 @@ int mopt_launch_rfo_scalar(mopt_ctx *ctx, hipStream_t st, int n, int batch, cons
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,
                     const double *d_Bg, const double *d_Be, const mopt::UpdateCoef *d_coef, double *d_gt_all,
-                    double *d_coefout, double *d_step) {
+                    double *d_coefout, double *d_step, const int *d_mf, int nmf) {
     using namespace mopt;
     mopt_scope sc(ctx, "rfo", 3);
     hipLaunchKernelGGL(k_vtg, dim3((n + 3) / 4, batch), dim3(256), 0, ctx->stream, n, d_Vt, d_gp, d_einfo, d_gt_all, (const double *)nullptr);
-    { const int rc = mopt_launch_rfo_scalar(ctx, ctx->stream, n, batch, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout); if (rc != MOPT_OK) return rc; }
+    { const int rc = mopt_launch_rfo_scalar(ctx, ctx->stream, n, batch, d_params, d_states, d_W, d_perm, d_einfo, d_gt_all, d_Bg, d_Be, d_coef, d_coefout, d_mf, nmf); if (rc != MOPT_OK) return rc; }
     hipLaunchKernelGGL(k_backtransform, dim3((n + 63) / 64, batch), dim3(1024), 0, ctx->stream, n, d_Vt, d_coefout, d_einfo, d_step);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;

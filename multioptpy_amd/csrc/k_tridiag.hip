@@ -27,7 +27,7 @@
 #include "ql_block.hpp"
 
 #ifndef MOPT_P3_DEFL_TOL
-#define MOPT_P3_DEFL_TOL 64.0  /* deflation tolerance per matrix entry in units of eps * max(|d|, |e| so far) */
+#define MOPT_P3_DEFL_TOL 2048.0  /* deflation tolerance per matrix entry in units of eps * max(|d|, |e| so far) */
 #endif
 #ifndef MOPT_P3_DEFLATE
 #define MOPT_P3_DEFLATE 1      /* early stop of the persistent tridiagonalisation on a diagonal trailing block, see k_tri_persist3 */

@@ -98,6 +98,7 @@ void *mopt_pin_get(mopt_ctx *ctx, size_t bytes) { return pin_get_impl(ctx, bytes
 
 
 void mopt_ws_release(mopt_ctx *ctx);
+void mopt_mf_release(mopt_ctx *ctx);
 
 extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     if (!ctx) return MOPT_E_ARG;
@@ -113,6 +114,7 @@ extern "C" int mopt_ctx_destroy(mopt_ctx *ctx) {
     hipStreamSynchronize(ctx->side3);
     hipEventDestroy(ctx->ev_fork5); hipEventDestroy(ctx->ev_join5);
     hipEventDestroy(ctx->ev_fork6); hipEventDestroy(ctx->ev_join6);
+    mopt_mf_release(ctx);
     mopt_ws_release(ctx);
     if (ctx->early_buf) hipFree(ctx->early_buf);
     if (ctx->defl.ev) { hipEventSynchronize(ctx->defl.ev); hipEventDestroy(ctx->defl.ev); }
@@ -532,6 +534,116 @@ static int ws_get(mopt_ctx *ctx, int n, int batch, bool own_h, bool bias, bool i
     }
     hit->stamp = ++g_ws_clock;
     *wk_out = hit->wk; *io_out = hit->io;
+    return MOPT_OK;
+}
+
+
+// ---- MF_RSIRFO in two halves (include/mopt_hip.h) ---------------------------------------------------------------------------------
+namespace {
+struct MfPending { RsirfoWork *wk = nullptr; RsirfoWork *own = nullptr; int n = 0; bool any_upd = false; bool valid = false; };
+std::map<mopt_ctx *, MfPending> g_mf;
+std::mutex g_mf_mu;
+void mf_drop(MfPending &p) { if (p.own) delete p.own; p = MfPending(); }
+}  // namespace
+void mopt_mf_release(mopt_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(g_mf_mu);
+    auto it = g_mf.find(ctx);
+    if (it != g_mf.end()) { mf_drop(it->second); g_mf.erase(it); }
+}
+
+extern "C" int mopt_mf_rsirfo_begin(mopt_ctx *ctx, int n, const mopt_rsirfo_params *params, const mopt_rsirfo_state *state, const double *hessian,
+                                    const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                                    const double *pre_g, double B_e, double *W_out, double *V_out, double *H_inplace, double *H_sym, int *hess_updated) {
+    if (bad_dims(ctx, n, 1)) return MOPT_E_ARG;
+    if (!params || !state || !geom || !B_g || !W_out || !V_out) { ctx->err = "mopt_mf_rsirfo_begin: null argument"; return MOPT_E_ARG; }
+    if (!hessian) { ctx->err = "Hessian matrix must be set"; return MOPT_E_STATE; }
+    if (params->rule < 0 || params->rule >= MOPT_RULE_COUNT) { ctx->err = "unknown update rule"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    MfPending *pend;
+    { std::lock_guard<std::mutex> lk(g_mf_mu); pend = &g_mf[ctx]; mf_drop(*pend); }
+    RsirfoWork *wkp = nullptr;
+    if (mopt_debug_poison_on()) {
+        pend->own = new (std::nothrow) RsirfoWork();
+        if (!pend->own) return MOPT_E_NOMEM;
+        TRY(pend->own->alloc(ctx, n, 1, true, bias_hessian != nullptr, H_inplace != nullptr));
+        wkp = pend->own;
+    } else {
+        void *io = nullptr;
+        TRY(ws_get(ctx, n, 1, true, bias_hessian != nullptr, H_inplace != nullptr, 256, &wkp, &io));
+    }
+    RsirfoWork &wk = *wkp;
+    const size_t nn = (size_t)n * n * sizeof(double), nv = (size_t)n * sizeof(double);
+    const int upd = (pre_geom && pre_g && state->has_prev) ? 1 : 0, rule = params->rule;
+    H2D(ctx, wk.x, geom, nv); H2D(ctx, wk.bg, B_g, nv); H2D(ctx, wk.g, g ? g : B_g, nv);
+    if (upd) { H2D(ctx, wk.px, pre_geom, nv); H2D(ctx, wk.pg, pre_g, nv); }
+    H2D(ctx, wk.be, &B_e, sizeof(double));
+    H2D(ctx, wk.params, params, sizeof(mopt_rsirfo_params));
+    H2D(ctx, wk.states, state, sizeof(mopt_rsirfo_state));
+    H2D(ctx, wk.rules, &rule, sizeof(int)); H2D(ctx, wk.do_update, &upd, sizeof(int));
+    H2D(ctx, wk.H, hessian, nn);
+    if (bias_hessian) H2D(ctx, wk.Bias, bias_hessian, nn);
+    if (upd) TRY(mopt_launch_hess_update(ctx, n, 1, wk.rules, wk.do_update, rule == MOPT_RULE_FLOWCHART, wk.x, wk.px, wk.g, wk.pg, wk.s, wk.y, wk.u, wk.Hy, wk.yd,
+                                         wk.Av, wk.coef, wk.info, wk.H, wk.Hinpl, wk.H, false));
+    std::vector<double> vt((size_t)n * n), w(n);
+    std::vector<int> perm(n);
+    int einfo[2] = {0, 0};
+    mopt::UpdateCoef hc;
+    hc.applied = 0;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        TRY(mopt_launch_project_hess(ctx, n, 1, wk.H, wk.Bias, wk.x, wk.Q, wk.W6, wk.A));
+        TRY(mopt_eigh_auto(ctx, wk, n, 1, false, /*preserve_A=*/false, nullptr));
+        D2H(ctx, einfo, wk.einfo, 2 * sizeof(int));
+        MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (!(einfo[1] & 8) || attempt == 1) break;
+        ctx->tri_no_persist = true;                          // hand-off time-out (shared GPU): once more with one launch per Householder step
+        ctx->n_retries += 1;
+    }
+    ctx->tri_no_persist = false;
+    if (einfo[1] & 4) { ctx->err = "mopt_mf_rsirfo_begin: the eigen-solver failed"; return MOPT_E_NUMERIC; }
+    D2H(ctx, w.data(), wk.eigw, nv); D2H(ctx, perm.data(), wk.perm, n * sizeof(int)); D2H(ctx, vt.data(), wk.Vt, nn);
+    if (upd) D2H(ctx, &hc, wk.coef, sizeof(hc));
+    if (H_sym) D2H(ctx, H_sym, wk.H, nn);
+    if (H_inplace) D2H(ctx, H_inplace, (upd ? wk.Hinpl : wk.H), nn);
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    const bool ident = (einfo[1] & 1) != 0;                  // non-finite spectrum: the consumers continue with (w = 1, V = I), rsirfo.py:365-372
+    for (int k = 0; k < n; ++k) {
+        W_out[k] = ident ? 1.0 : w[k];
+        const int r = ident ? k : perm[k];
+        for (int i = 0; i < n; ++i) V_out[(size_t)k * n + i] = ident ? (i == k ? 1.0 : 0.0) : vt[(size_t)r * n + i];
+    }
+    if (hess_updated) *hess_updated = upd ? hc.applied : 0;
+    pend->wk = wkp; pend->n = n; pend->any_upd = upd != 0; pend->valid = true;
+    return MOPT_OK;
+}
+
+extern "C" int mopt_mf_rsirfo_finish(mopt_ctx *ctx, int n, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const int *targets, int ntargets,
+                                     double *step) {
+    if (bad_dims(ctx, n, 1)) return MOPT_E_ARG;
+    if (!params || !state || !step || ntargets < 0 || ntargets > 8 || (ntargets > 0 && !targets)) { ctx->err = "mopt_mf_rsirfo_finish: bad argument"; return MOPT_E_ARG; }
+    MfPending *pend;
+    { std::lock_guard<std::mutex> lk(g_mf_mu); pend = &g_mf[ctx]; }
+    if (!pend->valid || pend->n != n || !pend->wk) { ctx->err = "mopt_mf_rsirfo_finish without a matching mopt_mf_rsirfo_begin"; return MOPT_E_STATE; }
+    hipSetDevice(ctx->device);
+    RsirfoWork &wk = *pend->wk;
+    int tg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t < ntargets; ++t) tg[t] = targets[t];
+    H2D(ctx, wk.params, params, sizeof(mopt_rsirfo_params));
+    H2D(ctx, wk.states, state, sizeof(mopt_rsirfo_state));
+    H2D(ctx, wk.rotcount, tg, sizeof(tg));                  // (the Jacobi route's rotation counters: free behind the solve)
+    TRY(mopt_launch_rfo(ctx, n, 1, wk.params, wk.states, wk.eigw, wk.perm, wk.einfo, wk.Vt, /*gradient: unprojected*/ wk.bg, wk.bg, wk.be,
+                        pend->any_upd ? wk.coef : nullptr, wk.gt_all, wk.coefout, wk.step, wk.rotcount, ntargets));
+    mopt_rsirfo_state st;
+    std::vector<double> sv(n);
+    D2H(ctx, &st, wk.states, sizeof(st)); D2H(ctx, sv.data(), wk.step, (size_t)n * sizeof(double));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    pend->valid = false;
+    int rc = MOPT_OK;
+    if (mopt_debug_poison_on()) rc = wk.check_canaries();
+    { std::lock_guard<std::mutex> lk(g_mf_mu); if (pend->own) { delete pend->own; pend->own = nullptr; pend->wk = nullptr; } }
+    if (rc != MOPT_OK) return rc;
+    if (st.jacobi_sweeps < 0) { ctx->err = "mopt_mf_rsirfo_finish: the eigen-solver failed"; return MOPT_E_NUMERIC; }
+    *state = st;
+    std::memcpy(step, sv.data(), (size_t)n * sizeof(double));
     return MOPT_OK;
 }
 

@@ -160,14 +160,14 @@ int mopt_launch_eig_gather(mopt_ctx *ctx, int n, int batch, const double *d_Vt, 
 // the three kernels of mopt_launch_rfo one by one (pipeline.hip overlaps the middle one with the back-transformation)
 int mopt_launch_rfo_scalar(mopt_ctx *ctx, hipStream_t st, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                            const double *d_W, const int *d_perm, const int *d_einfo, const double *d_gt_all, const double *d_Bg, const double *d_Be,
-                           const mopt::UpdateCoef *d_coef, double *d_coefout);
+                           const mopt::UpdateCoef *d_coef, double *d_coefout, const int *d_mf = nullptr, int nmf = 0);
 int mopt_launch_vtg(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_vec, const int *d_einfo, double *d_out,
                     const double *d_fallback = nullptr, hipStream_t st = nullptr);
 int mopt_launch_backtransform(mopt_ctx *ctx, int n, int batch, const double *d_Vt, const double *d_coef, const int *d_einfo, double *d_out);
 int mopt_launch_rfo(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_params *d_params, mopt_rsirfo_state *d_states,
                     const double *d_W, const int *d_perm, const int *d_einfo, const double *d_Vt, const double *d_gp,
                     const double *d_Bg, const double *d_Be, const mopt::UpdateCoef *d_coef, double *d_gt_all,
-                    double *d_coefout, double *d_step);
+                    double *d_coefout, double *d_step, const int *d_mf = nullptr, int nmf = 0);
 int mopt_launch_neb_force_var(mopt_ctx *ctx, int variant, int I, int N, int first, int count, const double *d_X, const double *d_E,
                               const double *d_G, int ci_active, double *d_F);
 int mopt_launch_norm_inf(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma);   // sigma = 1.0625 * ||A||_inf

@@ -37,7 +37,9 @@ __device__ inline bool ill_conditioned(const WaveRed &red, const double *w, int 
 template <bool FUSED>
 __device__ __forceinline__ void rfo_scalar_body(int n, int b, const mopt_rsirfo_params *params, mopt_rsirfo_state *states, const double *W, const int *perm,
                                                 const int *einfo, const double *gt_all_, const double *Bg, const double *Be, const UpdateCoef *coef,
-                                                double *coef_out_, int dbg, double *sm) {
+                                                double *coef_out_, int dbg, double *sm, const int *mf = nullptr, int nmf = 0) {
+    // mf != null: MF_RSIRFO (mf_rsirfo.py:128-265) -- the modes to reflect are the nmf ascending positions in mf (chosen by the mode follower on the
+    // host) instead of the first saddle_order non-zero ones, and the trust-radius update takes the curvature of the first of them
     auto SYNC = [] { if constexpr (FUSED) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
     // one latency-bound wave per image, usually running next to the back-transformation (pipeline.hip): highest issue priority on its SIMD
     __builtin_amdgcn_s_setprio(3);
@@ -97,15 +99,19 @@ __device__ __forceinline__ void rfo_scalar_body(int n, int b, const mopt_rsirfo_
     if (st.has_prev) {
         const double actual = energy - st.prev_energy;
         push3(st.actual, st.n_actual, actual);
-        if (st.n_predicted > 0) adjust_trust_radius(p, st, actual, st.predicted[st.n_predicted - 1], w0[0], gnorm);
+        if (st.n_predicted > 0) adjust_trust_radius(p, st, actual, st.predicted[st.n_predicted - 1], (mf && nmf > 0 && mf[0] >= 0 && mf[0] < n) ? w0[mf[0]] : w0[0], gnorm);
     }
     // --- image function (rsirfo.py:404-427): reflect (or, in NEB mode, remove) the first saddle_order modes with |lambda| > 1e-10.
     // P = I - c v v^T commutes with H on its eigenvectors: H* has the same eigenvectors, eigenvalue (1-c) lambda, g* = (1-c) g~.
     {
         int found = 0;
         const double f = p.neb_mode ? 0.0 : -1.0;
-        for (int i = 0; i < n && found < p.saddle_order; ++i) {
-            if (fabs(w0[i]) > 1e-10) { if (lane == 0) fac[i] = f; ++found; }
+        if (mf) {
+            for (int t = 0; t < nmf; ++t) { const int i = mf[t]; if (i >= 0 && i < n && fabs(w0[i]) > 1e-10 && lane == 0) fac[i] = f; }      // mf_rsirfo.py:207-214
+        } else {
+            for (int i = 0; i < n && found < p.saddle_order; ++i) {
+                if (fabs(w0[i]) > 1e-10) { if (lane == 0) fac[i] = f; ++found; }
+            }
         }
         SYNC();
     }

@@ -1,5 +1,6 @@
 """Drop-in for multioptpy/optimizer.py::CalculateMoveVector restricted to the quasi-Newton methods of the hot path
-(rsirfo_* -> RSIRFO, rsprfo_* -> EnhancedRSPRFO, crsirfo_* with a projection constraint -> CRSIRFO).
+(rsirfo_* -> RSIRFO, rsprfo_* -> EnhancedRSPRFO, crsirfo_* with a projection constraint -> CRSIRFO, [mw][s]mf_rsirfo_* -> MF_RSIRFO;
+SURVEY.md section 8 rows a15, a21).
 
 Same constructor, `initialization(method)` and `calc_move_vector(...)` signatures and return values as the reference
 (optimizer.py:259-307, 309-533, 740-818).  The step itself comes from the device-backed optimizer classes; the outer
@@ -15,13 +16,14 @@ from . import ops
 from .Optimizer.rsirfo import RSIRFO
 from .Optimizer.rsprfo import EnhancedRSPRFO
 from .Optimizer.crsirfo import CRSIRFO
+from .Optimizer.mf_rsirfo import MF_RSIRFO
 from .Optimizer.trust_radius import TrustRadius
 
 BOHR2ANGSTROMS = 0.52917721067          # Parameters/parameter.py:27
 
 _ENHANCEMENTS = ("lookahead", "lars", "linesearch", "gdiis", "kdiis", "adiis", "c2diis", "ediis", "coordinate_locking",
                  "component_wise_scaling", "gpr_step", "gan_step", "rl_step", "geodesic_step", "trim")
-_OTHER_NEWTON = ("mf_rsirfo",)
+_OTHER_NEWTON = ()
 
 
 class CalculateMoveVector:
@@ -70,7 +72,19 @@ class CalculateMoveVector:
             low = m.lower()
             if any(k in low for k in _ENHANCEMENTS) or any(k in low for k in _OTHER_NEWTON):
                 raise NotImplementedError(f"multioptpy_amd replaces the rsirfo_*/rsprfo_* step only, not '{m}'")
-            if "rsprfo" in low:
+            # (key groups in the order of the reference's quasi_newton_mapping, optimizer.py:68-254: the first group whose key is a substring wins)
+            if "mwsmf_rsirfo" in low:                             # optimizer.py:438-439: mass-weighted overlaps, static references
+                opt = MF_RSIRFO(method=m, saddle_order=self.saddle_order, element_list=self.element_list, trust_radius_max=self.max_trust_radius,
+                                trust_radius_min=self.min_trust_radius, adaptive_mode_following=False)
+            elif "mwmf_rsirfo" in low:                            # :441-442
+                opt = MF_RSIRFO(method=m, saddle_order=self.saddle_order, element_list=self.element_list, trust_radius_max=self.max_trust_radius,
+                                trust_radius_min=self.min_trust_radius)
+            elif "smf_rsirfo" in low:                             # :444-445: Cartesian overlaps, static references
+                opt = MF_RSIRFO(method=m, saddle_order=self.saddle_order, trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius,
+                                adaptive_mode_following=False)
+            elif "mf_rsirfo" in low:                              # :447-448
+                opt = MF_RSIRFO(method=m, saddle_order=self.saddle_order, trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius)
+            elif "rsprfo" in low:
                 opt = EnhancedRSPRFO(method=m, saddle_order=self.saddle_order, element_list=self.element_list,
                                      trust_radius_max=self.max_trust_radius, trust_radius_min=self.min_trust_radius)
             elif "crsirfo" in low and self.projection_constraint:

@@ -947,9 +947,71 @@ def g10c_lindh2007d3():
     print("G10c:", len(out["tags"]), "geometries")
 
 
+def g15_mf_rsirfo():
+    """G15: consecutive MF_RSIRFO.run calls of the reference (mode following: target index, EMA, gradient bias, mass-weighted overlaps,
+    Hungarian / greedy matching, static references) on the LJ surface, geometry advanced by the returned step."""
+    from multioptpy.Optimizer.mf_rsirfo import MF_RSIRFO
+    from multioptpy.Parameters.atomic_mass import atomic_mass
+    mixed = ["Ar", "Ne", "Kr", "He", "Xe", "Ar", "Ne", "Kr", "He", "Xe", "Ar", "Ne", "Kr", "He"]
+    cfgs = [
+        # (method string, saddle_order, N, steps, element_list or None, extra keywords, jitter)
+        ("mf_rsirfo_bofill", 1, 7, 6, None, {}, 0.3),
+        ("mf_rsirfo_fsb:1", 1, 7, 6, None, {}, 0.3),
+        ("mf_rsirfo_bofill:0:ema0.5", 1, 11, 6, None, {}, 0.3),
+        ("mf_rsirfo_bofill:ema0.3:grad0.3", 1, 11, 6, None, {}, 0.3),
+        ("mwmf_rsirfo_bofill", 1, 7, 6, mixed[:7], {}, 0.3),
+        ("mwsmf_rsirfo_fsb:1", 1, 11, 6, mixed[:11], {"adaptive_mode_following": False}, 0.3),
+        ("smf_rsirfo_bfgs", 1, 7, 5, None, {"adaptive_mode_following": False}, 0.3),
+        ("mf_rsirfo_bofill:1", 2, 11, 6, None, {}, 0.3),
+        ("mf_rsirfo_bofill", 2, 7, 5, None, {"use_hungarian": False}, 0.3),
+        ("mf_rsirfo_block_fsb", 1, 14, 5, mixed[:14], {}, 0.2),
+        ("mf_rsirfo_bfgs", 0, 7, 4, None, {}, 0.2),
+        ("mf_rsirfo_bofill:2", 1, 22, 4, None, {}, 0.3),
+    ]
+    out = {"ncfg": np.array(len(cfgs))}
+    for ci, (method, so, N, nst, elems, kw, jit) in enumerate(cfgs):
+        tag = f"m{ci:02d}"
+        n = 3 * N
+        x = cases.cluster(N, jitter=jit) * 0.95
+        H = cases.lj(x, hessian=True)[2].copy()
+        with quiet():
+            opt = MF_RSIRFO(method=method, saddle_order=so, element_list=elems, **kw)
+        out[tag + "_meta"] = np.array([N, so, nst])
+        out[tag + "_method"] = np.array(method)
+        out[tag + "_kw"] = np.array(repr(kw))
+        out[tag + "_masses"] = np.array([atomic_mass(e) for e in elems]) if elems else np.zeros(0)
+        out[tag + "_elems"] = np.array(elems if elems else [])
+        out[tag + "_H0"] = H.copy()
+        px = pg = pE = None
+        for k in range(nst):
+            E, G = cases.lj(x)
+            g = G.reshape(-1, 1)
+            xx = x.reshape(-1, 1).copy()
+            opt.set_hessian(H)               # optmain re-sets the same array every step (F7)
+            opt.set_bias_hessian(np.zeros((n, n)))
+            with quiet():
+                if k == 0:
+                    step = opt.run(xx, g, [], [], E, 0.0, [], [], g, [])
+                else:
+                    step = opt.run(xx, g, pg, px, E, pE, [], [], g, pg)
+            out[f"{tag}_s{k}_x"] = xx.copy()
+            out[f"{tag}_s{k}_g"] = g.copy()
+            out[f"{tag}_s{k}_E"] = np.array(E)
+            out[f"{tag}_s{k}_step"] = np.asarray(step).copy()
+            out[f"{tag}_s{k}_tr"] = np.array(opt.trust_radius)
+            out[f"{tag}_s{k}_pred"] = np.array(opt.predicted_energy_changes[-1])
+            out[f"{tag}_s{k}_targets"] = np.array(opt.mode_follower.reference_indices, dtype=np.int64)
+            out[f"{tag}_s{k}_Hself"] = np.array(opt.hessian).copy()
+            out[f"{tag}_s{k}_Hcaller"] = H.copy()
+            px, pg, pE = xx, g, E
+            x = (xx - step).reshape(-1, 3)
+    np.savez_compressed(os.path.join(HERE, "g15_mf_rsirfo.npz"), **out)
+    print("G15:", len(cfgs), "traces")
+
+
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g11", "g12", "g13", "g14", "g15"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -966,6 +1028,8 @@ if __name__ == "__main__":
         g10b_model_hessian_variants()
     if "g10c" in which:
         g10c_lindh2007d3()
+    if "g15" in which:
+        g15_mf_rsirfo()
     if "g11" in which:
         g11_afir()
     if "g12" in which:

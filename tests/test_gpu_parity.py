@@ -339,6 +339,27 @@ def test_rsprfo_traces_vs_reference():
     print("RSPRFO worst step deviation from the reference:", worst)
 
 
+def test_mf_rsirfo_traces_vs_reference():
+    """G15: MF_RSIRFO (mode-following RS-I-RFO: mopt_mf_rsirfo_begin / ModeFollowing on the host / mopt_mf_rsirfo_finish) against twelve
+    traces of the reference's class: step, trust radius, predicted change, matched mode indices, both Hessian objects (F7)."""
+    from multioptpy_amd.Optimizer.mf_rsirfo import MF_RSIRFO
+    import test_oracle_golden as tog
+    z = np.load(os.path.join(G, "g15_mf_rsirfo.npz"))
+    worst = tog._check_mf(z, lambda method, so, elems, masses, kw: MF_RSIRFO(method=method, saddle_order=so, element_list=elems, **kw), 1e-8)
+    print("MF_RSIRFO worst step deviation from the reference:", worst)
+
+
+def test_mf_rsirfo_through_the_dispatcher():
+    """optimizer.py:438-448: the four key families reach MF_RSIRFO with the reference's keyword sets."""
+    from multioptpy_amd.optimizer import CalculateMoveVector
+    from multioptpy_amd.Optimizer.mf_rsirfo import MF_RSIRFO
+    cmv = CalculateMoveVector(0.5, ["Ar"] * 7, saddle_order=1)
+    for key, mw, adaptive in (("mwsmf_rsirfo_bofill", True, False), ("mwmf_rsirfo_fsb:1", True, True), ("smf_rsirfo_bfgs", False, False), ("mf_rsirfo_bofill:ema0.5", False, True)):
+        opt = cmv.initialization([key])[0]
+        assert isinstance(opt, MF_RSIRFO) and opt.DELTA == 0.5
+        assert (opt.mode_follower.mass_weights is not None) == mw and opt.mode_follower.adaptive == adaptive, key
+
+
 @pytest.mark.parametrize("natoms", [7, 11, 22])
 def test_rsprfo_surplus_negative_modes_vs_oracle(natoms):
     """A start geometry whose exact Hessian has SEVERAL negative eigenvalues (saddle order 1): the surplus ones are shifted to

@@ -93,6 +93,19 @@ def test_poisoned_workspace_single_geometry(N):
     print("poisoned workspace, single geometry n =", 3 * N, ": deviation from the oracle", err)
 
 
+def test_poisoned_workspace_mf_rsirfo_and_small_kernels_general_path():
+    """MF_RSIRFO's two-call form (the workspace lives between mopt_mf_rsirfo_begin and _finish) and EnhancedRSPRFO on poisoned, guarded
+    workspaces (the one-workgroup kernels are bypassed in this mode: the general pipeline runs) against the reference's traces."""
+    from multioptpy_amd import _lib
+    import test_gpu_parity as tp
+    _lib.lib().mopt_debug_poison(1)
+    try:
+        tp.test_mf_rsirfo_traces_vs_reference()
+        tp.test_rsprfo_traces_vs_reference()
+    finally:
+        _lib.lib().mopt_debug_poison(0)
+
+
 def test_poison_mode_detects_an_out_of_bounds_write():
     """The checker itself: a deliberately oversized copy into a band array (through the public upload call with a forged image count is
     not possible, so the test corrupts a gap with hipMemset through the runtime) must be reported as MOPT_E_STATE."""

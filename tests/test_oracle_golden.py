@@ -530,3 +530,56 @@ def test_oracle_lindh2007d3_vs_reference():
         assert np.abs(H - z[tag + "_H"]).max() < 1e-12, tag
         assert np.abs(mh.approx_hessian(x, el, g, "some_unknown_name") - z[tag + "_Hfallback"]).max() < 1e-12, tag
         assert np.abs(mh.approx_hessian(x, el, g, "lindh2007d3_clip") - z[tag + "_Hclip"]).max() < 1e-12, tag
+
+
+def _replay_mf(z, tag, make):
+    """Feeds the recorded inputs of a G15 trace to an MF_RSIRFO object built by make(method, saddle_order, elems, masses, kw); yields (k, opt, step)."""
+    N, so, nst = (int(v) for v in z[tag + "_meta"])
+    n = 3 * N
+    method = str(z[tag + "_method"])
+    kw = eval(str(z[tag + "_kw"]), {"__builtins__": {}}, {"True": True, "False": False})      # a literal dict written by make_golden.py
+    elems = [str(e) for e in z[tag + "_elems"]] or None
+    masses = z[tag + "_masses"] if z[tag + "_masses"].size else None
+    opt = make(method, so, elems, masses, kw)
+    H = z[tag + "_H0"].copy()
+    px = pg = pE = None
+    for k in range(nst):
+        x, g, E = z[f"{tag}_s{k}_x"], z[f"{tag}_s{k}_g"], float(z[f"{tag}_s{k}_E"])
+        opt.set_hessian(H)
+        opt.set_bias_hessian(np.zeros((n, n)))
+        if k == 0:
+            step = opt.run(x.copy(), g.copy(), [], [], E, 0.0, [], [], g.copy(), [])
+        else:
+            step = opt.run(x.copy(), g.copy(), pg, px, E, pE, [], [], g.copy(), pg)
+        yield k, opt, np.asarray(step), H
+        px, pg, pE = x, g, E
+
+
+def _check_mf(z, make, tol):
+    worst = 0.0
+    for i in range(int(z["ncfg"])):
+        tag = f"m{i:02d}"
+        for k, opt, step, H in _replay_mf(z, tag, make):
+            ref = z[f"{tag}_s{k}_step"]
+            err = np.abs(step - ref).max()
+            worst = max(worst, err)
+            assert err < tol * max(1.0, np.abs(ref).max()), (tag, k, err)
+            assert abs(opt.trust_radius - float(z[f"{tag}_s{k}_tr"])) < 1e-12, (tag, k)
+            pr = float(z[f"{tag}_s{k}_pred"])
+            assert abs(opt.predicted_energy_changes[-1] - pr) < tol * max(1.0, abs(pr)), (tag, k)
+            assert list(opt.mode_follower.reference_indices) == [int(t) for t in z[f"{tag}_s{k}_targets"]], (tag, k)
+            assert np.abs(np.asarray(opt.hessian) - z[f"{tag}_s{k}_Hself"]).max() < tol, (tag, k)
+            assert np.abs(H - z[f"{tag}_s{k}_Hcaller"]).max() < tol, (tag, k)        # F7: the caller's array after the in-place update
+    return worst
+
+
+def test_g15_mf_rsirfo_traces():
+    """G15: the oracle's MF_RSIRFO + ModeFollowing against twelve traces of the reference's class (target index, EMA, gradient bias,
+    mass-weighted overlaps, Hungarian / greedy matching, static references, saddle orders 0 .. 2)."""
+    from oracle.mf_rsirfo import MF_RSIRFO
+    z = np.load(os.path.join(G, "g15_mf_rsirfo.npz"))
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        worst = _check_mf(z, lambda method, so, elems, masses, kw: MF_RSIRFO(masses=masses, method=method, saddle_order=so, **kw), 1e-9)
+    print("oracle MF_RSIRFO vs reference: worst step deviation", worst)
