@@ -75,8 +75,10 @@ class ProjectOutConstrain:
         self.names = list(constraint_name)
         self.atoms = [[int(a) for a in lst] for lst in constraint_atoms_list]
         for nm in self.names:
-            if nm not in ("bond", "angle", "dihedral", "x", "y", "z"):
+            if nm not in ("bond", "fbond", "angle", "dihedral", "x", "y", "z", "rot", "eigvec", "atoms_pair"):
                 raise NotImplementedError(f"constraint '{nm}' is not restated by the oracle")
+        self.projection_vec = []
+        self.arbitrary_proj_vec = []
         self.init_tag = True
         self.reference_scale = None
         self.alpha_smoothing = 0.7
@@ -85,22 +87,69 @@ class ProjectOutConstrain:
         self.last_shake_iter = 0
         self.init_constraint = None
 
-    def values(self, x):
+    @staticmethod
+    def kabsch(P, Q):
+        """Utils/calc_tools.py:412-425: both arguments are centred IN PLACE; returns (rotated P, Q)."""
+        P -= np.array([np.mean(P.T[0]), np.mean(P.T[1]), np.mean(P.T[2])])
+        Q -= np.array([np.mean(Q.T[0]), np.mean(Q.T[1]), np.mean(Q.T[2])])
+        U, S, Vt = np.linalg.svd(np.dot(P.T, Q))
+        R = np.dot(Vt.T, U.T)
+        if np.linalg.det(R) < 0:
+            Vt[-1, :] *= -1
+            R = np.dot(Vt.T, U.T)
+        return np.dot(R, P.T).T, Q
+
+    def values(self, x, obj=None, hessian=None):
+        """constraint_condition.py:371-441 (obj: the geometry object the special kinds keep)"""
         out = []
+        self.projection_vec = []
+        arb = []
         for nm, at in zip(self.names, self.atoms):
             a = [i - 1 for i in at]
             if nm == "bond":
                 out.append(np.linalg.norm(x[a[0]] - x[a[1]]))
+            elif nm == "fbond":
+                d = at[-1]
+                f1, f2 = np.array(at[:d], dtype=np.int32) - 1, np.array(at[d:], dtype=np.int32) - 1
+                out.append(np.linalg.norm(np.mean(x[f1], axis=0) - np.mean(x[f2], axis=0)))
             elif nm == "angle":
                 out.append(angle_from_vec(x[a[0]] - x[a[1]], x[a[2]] - x[a[1]]))
             elif nm == "dihedral":
                 out.append(dihedral_from_vec(x[a[0]] - x[a[1]], x[a[1]] - x[a[2]], x[a[2]] - x[a[3]]))
-            else:
+            elif nm in ("x", "y", "z"):
                 out.append(x[a[0]]["xyz".index(nm)])
+            elif nm == "rot":
+                out.append(obj)
+            elif nm == "eigvec":
+                if hessian is None:
+                    raise Exception("error (Hessian is required for eigvec constraint)")
+                w, v = np.linalg.eigh(np.array(hessian))
+                valid = np.where(np.abs(w) > 1.0e-10)[0]
+                srt = valid[np.argsort(w[valid])]
+                self.projection_vec.append(v[:, srt[int(at[0])]])
+                out.append(obj)
+            else:
+                vec = np.zeros_like(x)
+                vec[a[0]] = -x[a[0]] + x[a[1]]
+                vec[a[1]] = -x[a[1]] + x[a[0]]
+                nv = np.linalg.norm(vec)
+                if nv < 1.0e-10:
+                    raise Exception("error (the distance between the pair atoms is too small)")
+                arb.append((vec / nv).reshape(-1, 1))
+                out.append(obj)
+        ortho = []
+        for v in arb:
+            w_ = v.copy()
+            for u in ortho:
+                w_ -= np.dot(u.T, w_) * u
+            nw = np.linalg.norm(w_)
+            if nw > 1e-10:
+                ortho.append(w_ / nw)
+        self.arbitrary_proj_vec = ortho
         return out
 
     def initialize(self, x, **kw):
-        vals = self.values(np.asarray(x, dtype=float))
+        vals = self.values(np.asarray(x, dtype=float), obj=x, hessian=kw.get("hessian"))
         if self.init_tag:
             self.init_constraint = list(vals)
             self.init_tag = False
@@ -111,7 +160,16 @@ class ProjectOutConstrain:
         given, Utils/calc_tools.py:750-758) -- CRSIRFO relies on that, see there."""
         x = coord if isinstance(coord, np.ndarray) and coord.dtype == np.float64 else np.array(coord, dtype=float)
         if self.init_tag or self.init_constraint is None:
-            self.initialize(x)
+            self.initialize(x, hessian=hessian)
+        for nm, at, tgt in zip(self.names, self.atoms, self.init_constraint):          # constraint_condition.py:481-497
+            if nm == "rot":
+                t = np.array(at, dtype=np.int32) - 1
+                centre = np.mean(x[t], axis=0)
+                rot, _ = self.kabsch(x[t], tgt[t])
+                x[t] = rot + centre
+            elif nm in ("eigvec", "atoms_pair"):
+                x, _ = self.kabsch(x, tgt)
+        special = ("rot", "eigvec", "atoms_pair")
         final = 0
         for jter in range(10000):
             final = jter
@@ -119,14 +177,27 @@ class ProjectOutConstrain:
                 a = [i - 1 for i in at]
                 if nm == "bond":
                     x = set_distance(x, a[0], a[1], tgt)
+                elif nm == "fbond":
+                    d = at[-1]
+                    f1, f2 = np.array(at[:d], dtype=np.int32) - 1, np.array(at[d:], dtype=np.int32) - 1
+                    c1 = sum((x[i] for i in f1), np.zeros(3)) / len(f1)
+                    c2 = sum((x[i] for i in f2), np.zeros(3)) / len(f2)
+                    vec = c2 - c1
+                    nv = np.linalg.norm(vec)
+                    for i in f1:
+                        x[i] = x[i] - (tgt - nv) * (vec / nv) * 0.5
+                    for i in f2:
+                        x[i] = x[i] + (tgt - nv) * (vec / nv) * 0.5
                 elif nm == "angle":
                     x = set_angle(x, a[0], a[1], a[2], tgt)
                 elif nm == "dihedral":
                     x = set_dihedral(x, a[0], a[1], a[2], a[3], tgt)
-                else:
+                elif nm in ("x", "y", "z"):
                     x[a[0]]["xyz".index(nm)] = tgt
-            cur = np.array(self.values(x))
-            if len(cur) == 0 or np.linalg.norm(cur - np.array(self.init_constraint)) < 1.0e-10:
+            vals = self.initialize(x, hessian=hessian)
+            cur = [v for v, nm in zip(vals, self.names) if nm not in special]
+            ref = [v for v, nm in zip(self.init_constraint, self.names) if nm not in special]
+            if len(cur) == 0 or np.linalg.norm(np.array(cur, dtype=float) - np.array(ref, dtype=float)) < 1.0e-10:
                 break
         self.last_shake_iter = final
         return x
@@ -135,9 +206,46 @@ class ProjectOutConstrain:
         x = np.asarray(x, dtype=float).reshape(-1, 3)
         n = x.size
         rows = []
+        npv = nav = 0
         for nm, at in zip(self.names, self.atoms):
             a = [i - 1 for i in at]
             v = np.zeros(n)
+            if nm == "fbond":
+                # the reference differentiates |mean(x[f1]) - mean(x[f2])| with autograd (redundant_coordinate.py:328-332)
+                d = at[-1]
+                f1, f2 = np.array(at[:d], dtype=np.int32) - 1, np.array(at[d:], dtype=np.int32) - 1
+                dv = np.mean(x[f1], axis=0) - np.mean(x[f2], axis=0)
+                u = dv / np.linalg.norm(dv)
+                for i in f1:
+                    v[3 * i:3 * i + 3] += u / len(f1)
+                for i in f2:
+                    v[3 * i:3 * i + 3] -= u / len(f2)
+                rows.append(v)
+                continue
+            if nm == "rot":                                        # constraint_condition.py:764-782
+                t = np.array(at, dtype=np.int32) - 1
+                cg = x[t] - np.mean(x[t], axis=0)
+                Bm = np.zeros((3 * len(t), n))
+                for j in range(len(t)):
+                    i = t[j]
+                    Bm[3 * j][3 * i + 1] = cg[i][2]
+                    Bm[3 * j][3 * i + 2] = -1 * cg[i][1]
+                    Bm[3 * j + 1][3 * i + 0] = -1 * cg[i][2]
+                    Bm[3 * j + 1][3 * i + 2] = cg[i][0]
+                    Bm[3 * j + 2][3 * i + 0] = cg[i][1]
+                    Bm[3 * j + 2][3 * i + 1] = -1 * cg[i][0]
+                rows.extend(list(Bm))
+                continue
+            if nm == "eigvec":
+                if npv < len(self.projection_vec):
+                    rows.append(self.projection_vec[npv])
+                    npv += 1
+                continue
+            if nm == "atoms_pair":
+                if nav < len(self.arbitrary_proj_vec):
+                    rows.append(self.arbitrary_proj_vec[nav].reshape(-1))
+                    nav += 1
+                continue
             if nm == "bond":
                 _, b = stretch2(x[a])
                 for k, i in enumerate(a):

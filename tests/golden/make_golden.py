@@ -1009,9 +1009,58 @@ def g15_mf_rsirfo():
     print("G15:", len(cfgs), "traces")
 
 
+def g12b_constraint_kinds():
+    """G12b: the constraint kinds fbond / rot / eigvec / atoms_pair of ProjectOutConstrain (constraint_condition.py:385-437, 481-497,
+    556-612, 764-797) next to a plain bond: initial values, constraint rows, gradient projection, two Hessian projections, and the
+    alignment + SHAKE-like adjustment (which centres the stored initial geometry in place)."""
+    from multioptpy.Constraint.constraint_condition import ProjectOutConstrain
+    from multioptpy.ModelHessian.fischerd3old import FischerD3ApproxHessianOld
+    elems, xyz = _read_xyz("/root/reference/test/aldol_rxn.xyz")
+    x0 = xyz / cases.BOHR2ANG
+    N = len(elems)
+    n = 3 * N
+    with quiet():
+        K = FischerD3ApproxHessianOld().main(x0.copy(), list(elems), np.zeros_like(x0))
+    Hm = K + np.diag(0.05 + 0.01 * np.arange(n) / n)          # no zero modes, no exact degeneracies: the eigvec kind picks a well-defined mode
+    rng = np.random.default_rng(1212)
+    sets = [
+        (["fbond", "bond"], [[1, 2, 3, 4, 2], [5, 6]]),
+        (["rot", "bond"], [[1, 2, 3], [4, 5]]),
+        (["eigvec", "bond"], [[1], [2, 3]]),
+        (["atoms_pair", "atoms_pair", "angle"], [[1, 2], [3, 4], [5, 1, 6]]),
+        (["fbond", "rot", "eigvec", "atoms_pair", "x"], [[4, 5, 6, 7, 8, 3], [1, 2, 3], [2], [9, 10], [11]]),
+    ]
+    out = {"x0": x0, "elems": np.array(elems), "Hm": Hm, "nsets": np.array(len(sets))}
+    for si, (names, atoms) in enumerate(sets):
+        tag = f"k{si}"
+        out[tag + "_names"] = np.array(names)
+        out[tag + "_atoms_flat"] = np.array([a for lst in atoms for a in lst])
+        out[tag + "_atoms_len"] = np.array([len(lst) for lst in atoms])
+        with quiet():
+            pc = ProjectOutConstrain(list(names), [list(a) for a in atoms])
+            xinit = x0.copy()
+            init = pc.initialize(xinit, hessian=Hm)
+            out[tag + "_init_scalars"] = np.array([float(v) for v, nm in zip(init, names) if nm not in ("rot", "eigvec", "atoms_pair")])
+            for k in range(2):
+                x = x0 + rng.normal(0, 0.03, x0.shape)
+                g = rng.normal(size=(N, 3))
+                H = Hm + 0.05 * np.eye(n) * k
+                out[f"{tag}_p{k}_x"], out[f"{tag}_p{k}_g"], out[f"{tag}_p{k}_Hin"] = x, g, H
+                out[f"{tag}_p{k}_B"] = np.array(pc._get_all_constraint_vectors(x))
+                out[f"{tag}_p{k}_gproj"] = np.array(pc.calc_project_out_grad(x.copy(), g.copy()))
+                out[f"{tag}_p{k}_Hproj"] = np.array(pc.calc_project_out_hess(x.copy(), g.copy(), H.copy()))
+            xa = x0 + rng.normal(0, 0.05, x0.shape)
+            out[tag + "_shake_in"] = xa.copy()
+            out[tag + "_shake_out"] = np.array(pc.adjust_init_coord(xa.copy(), hessian=Hm))
+            out[tag + "_shake_iters"] = np.array(pc.last_shake_iter)
+            out[tag + "_xinit_after"] = xinit.copy()         # the initial geometry object after the Kabsch call centred it
+    np.savez_compressed(os.path.join(HERE, "g12b_constraint_kinds.npz"), **out)
+    print("G12b written:", len(sets), "constraint sets")
+
+
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g11", "g12", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g11", "g12", "g12b", "g13", "g14", "g15"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -1030,6 +1079,8 @@ if __name__ == "__main__":
         g10c_lindh2007d3()
     if "g15" in which:
         g15_mf_rsirfo()
+    if "g12b" in which:
+        g12b_constraint_kinds()
     if "g11" in which:
         g11_afir()
     if "g12" in which:

@@ -5,6 +5,8 @@
     Calculator/lj_calculation_tools.py:340-353 -> neb.py:794-804): dense molecular spectra with the six-fold TR/rot zero
     cluster, vs the oracle.
 Tolerance: 1e-8 (north_star) on geometries in angstrom; eigen-solver residuals relative to ||A||_inf."""
+import os
+
 import numpy as np
 import pytest
 
@@ -649,6 +651,15 @@ def test_constraint_hessian_projection_vs_reference():
         out = pc.calc_project_out_hess(z[f"p{k}_x"], z[f"p{k}_g"], z[f"p{k}_Hin"])
         err = np.abs(out - z[f"p{k}_Hproj"]).max()
         assert err < 1e-8 * max(1.0, np.abs(z[f"p{k}_Hproj"]).max()), (k, err)
+
+
+def test_constraint_kinds_fbond_rot_eigvec_atoms_pair_vs_reference():
+    """G12b: the plugin class with the constraint kinds fbond / rot / eigvec / atoms_pair (eigen-solve of the eigvec kind, Kabsch alignment
+    and the Hessian projection on the device) against the reference's outputs on five constraint sets."""
+    import test_oracle_golden as tog
+    from multioptpy_amd.Constraint.constraint_condition import ProjectOutConstrain
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g12b_constraint_kinds.npz"))
+    tog._check_g12b(z, lambda names, atoms: ProjectOutConstrain(names, atoms), lambda pc, x: pc._get_all_constraint_vectors(x), 1e-8)
 
 
 def test_crsirfo_traces_vs_reference():

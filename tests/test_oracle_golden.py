@@ -471,7 +471,49 @@ def test_g12_constraint_host_parts_of_the_plugin_class():
         assert np.abs(pc.calc_project_out_grad(z[f"p{k}_x"], z[f"p{k}_g"]) - z[f"p{k}_gproj"]).max() < 1e-13
     assert np.abs(pc.adjust_init_coord(z["shake_in"].copy()) - z["shake_out"]).max() < 1e-13
     with pytest.raises(NotImplementedError):
-        ProjectOutConstrain(["rot"], [[1, 2, 3]])
+        ProjectOutConstrain(["no_such_kind"], [[1, 2, 3]])
+
+
+def _g12b_sets(z):
+    for si in range(int(z["nsets"])):
+        tag = f"k{si}"
+        names = [str(s) for s in z[tag + "_names"]]
+        atoms, k = [], 0
+        for ln in z[tag + "_atoms_len"]:
+            atoms.append([int(a) for a in z[tag + "_atoms_flat"][k:k + int(ln)]])
+            k += int(ln)
+        yield tag, names, atoms
+
+
+def _check_g12b(z, make, rows_of, tol_h):
+    """ProjectOutConstrain objects built by make(names, atoms) against G12b: initial values, rows (up to sign), projections, adjustment."""
+    special = ("rot", "eigvec", "atoms_pair")
+    for tag, names, atoms in _g12b_sets(z):
+        pc = make(names, atoms)
+        xinit = z["x0"].copy()
+        init = pc.initialize(xinit, hessian=z["Hm"])
+        sc = np.array([float(v) for v, nm in zip(init, names) if nm not in special])
+        assert sc.size == z[tag + "_init_scalars"].size and (sc.size == 0 or np.abs(sc - z[tag + "_init_scalars"]).max() < 1e-13), tag
+        for k in range(2):
+            x, g, H = z[f"{tag}_p{k}_x"], z[f"{tag}_p{k}_g"], z[f"{tag}_p{k}_Hin"]
+            B = rows_of(pc, x)
+            assert B.shape == z[f"{tag}_p{k}_B"].shape, tag
+            for i in range(len(B)):
+                assert min(np.abs(B[i] - z[f"{tag}_p{k}_B"][i]).max(), np.abs(B[i] + z[f"{tag}_p{k}_B"][i]).max()) < 1e-10, (tag, k, i)
+            assert np.abs(pc.calc_project_out_grad(x.copy(), g.copy()) - z[f"{tag}_p{k}_gproj"]).max() < 1e-11, (tag, k)
+            if tol_h is not None:
+                assert np.abs(pc.calc_project_out_hess(x.copy(), g.copy(), H.copy()) - z[f"{tag}_p{k}_Hproj"]).max() < tol_h, (tag, k)
+        out = pc.adjust_init_coord(z[tag + "_shake_in"].copy(), hessian=z["Hm"])
+        assert np.abs(out - z[tag + "_shake_out"]).max() < 1e-10, tag
+        assert pc.last_shake_iter == int(z[tag + "_shake_iters"]), tag
+        assert np.abs(xinit - z[tag + "_xinit_after"]).max() < 1e-12, tag           # the stored initial geometry was centred in place
+
+
+def test_g12b_constraint_kinds_oracle_vs_reference():
+    """G12b: fbond / rot / eigvec / atoms_pair (five constraint sets on the aldol geometry) -- the oracle against the reference's outputs."""
+    from oracle import constraint as oc
+    z = np.load(os.path.join(G, "g12b_constraint_kinds.npz"))
+    _check_g12b(z, lambda names, atoms: oc.ProjectOutConstrain(names, atoms), lambda pc, x: pc.constraint_vectors(x), 1e-9)
 
 
 def test_g13_path_tools_oracle_and_host_glue_vs_reference():
