@@ -7,8 +7,8 @@ coordination-number scaled D3 pairs (``fischerd3``, ModelHessian/fischerd3.py:17
 ModelHessian/fischer.py:216-236), Schlegel's model (``schlegel``, ModelHessian/schlegel.py:66-144), the Morse model (``morse``,
 ModelHessian/morse.py:50-106) and Lindh's 2007 model with D3 dispersion (``lindh2007d3``, ModelHessian/lindh2007d3.py:777-822) -- which is
 also what a name the dispatcher does not know falls back to, as in the reference (approx_hessian.py:88-91) -- and the ``clip`` modifier
-(approx_hessian.py:104-120).  The Swart, Lindh-1995 / -D2 / -D4, Schlegel-D3/D4, Fischer-D4 and GFN models and the ``ts`` / ``sr``
-modifiers raise NotImplementedError; there is no CPU fallback.
+(approx_hessian.py:104-120).  The Swart, Lindh-1995 / -D2 / -D4, Schlegel-D3/D4, Fischer-D4 and GFN models and the ``sr``
+modifier raise NotImplementedError (``ts``: round 3, eigen-solve on the device); there is no CPU fallback.
 
 Per-element parameters (covalent radii, C6, van-der-Waals radii, r4/r2, D3 scaling) are the numbers the reference's
 ``multioptpy/Parameters`` functions return, kept as data in ``element_tables.json`` (tools/extract_element_tables.py)."""
@@ -23,6 +23,7 @@ from .._lib import lib, check, f64, ptr
 
 MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER, MODEL_SCHLEGEL, MODEL_MORSE, MODEL_LINDH2007D3 = 0, 1, 2, 3, 4, 5
 FLAG_CLIP = 1
+FLAG_TS = 2          # (host-side flag of this module: the `ts` modifier; never passed to the C ABI)
 _TAB = None
 
 
@@ -105,12 +106,35 @@ def model_kind(approx_hess_type, with_flags=False):
         raise NotImplementedError(f"model Hessian '{approx_hess_type}' is not available on the device (available: fischerd3old, fischerd3, "
                                   "fischer, schlegel, morse, lindh2007d3)")
     flags = 0
-    for suffix in ("ts", "sr"):                          # approx_hessian.py:93-102: modifiers applied after the model (the tests see the whole name)
-        if suffix in name:
-            raise NotImplementedError(f"model Hessian modifier '{suffix}' is not available on the device")
+    # approx_hessian.py:93-110: modifiers applied after the model, in the order ts, sr, clip (the tests see the whole name)
+    if "sr" in name:
+        raise NotImplementedError("model Hessian modifier 'sr' (short-range correction, ModelHessian/shortrange.py) is not available on the device")
+    if "ts" in name:
+        flags |= FLAG_TS
     if "clip" in name:
+        if flags & FLAG_TS:
+            raise NotImplementedError("model Hessian modifiers 'ts' and 'clip' together are not available on the device")
         flags |= FLAG_CLIP
     return (kind, flags) if with_flags else kind
+
+
+def ts_modification(H):
+    """TransitionStateHessian.create_ts_hessian (ModelHessian/tshess.py:14-40): unless the model Hessian already has an eigenvalue below -1e-8,
+    its lowest mode behind the leading |lambda| < 1e-8 ones is reflected: sym((1 - 2 v v^T) H) = H - v (H v)^T - (H v) v^T.  The eigen-solve
+    runs on the device (ops.eigh); the rank-two correction is O(n^2) host work on the array that is being handed to the caller anyway."""
+    from .. import ops
+    w, v = ops.eigh(np.ascontiguousarray(H, dtype=np.float64))
+    if np.any(w < -1e-8):
+        return H
+    count = 0
+    for lam in w:
+        if abs(lam) < 1e-8:
+            count += 1
+        else:
+            break
+    t = np.array(v[:, count])
+    Ht = H @ t
+    return H - np.outer(t, H.T @ t) - np.outer(Ht, t)
 
 
 class ApproxHessian:
@@ -125,7 +149,9 @@ class ApproxHessian:
         G = None if cart_gradient is None else f64(cart_gradient).reshape(-1, 3)
         H = np.empty((3 * N, 3 * N))
         c = _lib.ctx(self.device)
-        check(lib().mopt_model_hessian_ex(c, kind, flags, N, 1, ptr(X), ptr(par), ptr(d3), ptr(G), 1, ptr(H)), c)
+        check(lib().mopt_model_hessian_ex(c, kind, flags & FLAG_CLIP, N, 1, ptr(X), ptr(par), ptr(d3), ptr(G), 1, ptr(H)), c)
+        if flags & FLAG_TS:
+            H = ts_modification(H)
         return H
 
     def batch(self, coords, element_list, approx_hess_type="fischerd3old", project=True, cart_gradients=None):
@@ -137,5 +163,8 @@ class ApproxHessian:
         G = None if cart_gradients is None else f64(cart_gradients).reshape(I, N, 3)
         H = np.empty((I, 3 * N, 3 * N))
         c = _lib.ctx(self.device)
-        check(lib().mopt_model_hessian_ex(c, kind, flags, N, I, ptr(X), ptr(par), ptr(d3), ptr(G), 1 if project else 0, ptr(H)), c)
+        check(lib().mopt_model_hessian_ex(c, kind, flags & FLAG_CLIP, N, I, ptr(X), ptr(par), ptr(d3), ptr(G), 1 if project else 0, ptr(H)), c)
+        if flags & FLAG_TS:
+            for i in range(I):
+                H[i] = ts_modification(H[i])
         return H

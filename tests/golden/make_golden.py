@@ -1058,9 +1058,30 @@ def g12b_constraint_kinds():
     print("G12b written:", len(sets), "constraint sets")
 
 
+def g10d_ts_modifier():
+    """G10d: the `ts` modifier of ApproxHessian.main (approx_hessian.py:95-98 -> ModelHessian/tshess.py:14-40: the lowest non-zero mode of
+    the model Hessian is reflected) on G10's geometries, on top of fischerd3old and of schlegel."""
+    from multioptpy.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(HERE, "g10_model_hessian.npz"))
+    out = {"tags": z["tags"]}
+    for tag in z["tags"]:
+        x, elems = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]]
+        g = np.zeros_like(x)
+        out[tag + "_x"], out[tag + "_elems"] = x, z[tag + "_elems"]
+        for model in ("fischerd3old", "schlegel"):
+            try:
+                with quiet():
+                    Hm = ApproxHessian().main(x.copy(), list(elems), g.copy(), approx_hess_type=model + "_ts")
+                out[f"{tag}_Hts_{model}"] = np.array(Hm)
+            except IndexError:                                # every eigenvalue below 1e-8 in magnitude (tshess.py:31 indexes past the end)
+                out[f"{tag}_Hts_{model}"] = np.zeros(0)
+    np.savez_compressed(os.path.join(HERE, "g10d_ts_modifier.npz"), **out)
+    print("G10d:", len(out["tags"]), "geometries")
+
+
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g11", "g12", "g12b", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g10d", "g11", "g12", "g12b", "g13", "g14", "g15"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -1079,6 +1100,8 @@ if __name__ == "__main__":
         g10c_lindh2007d3()
     if "g15" in which:
         g15_mf_rsirfo()
+    if "g10d" in which:
+        g10d_ts_modifier()
     if "g12b" in which:
         g12b_constraint_kinds()
     if "g11" in which:

@@ -431,6 +431,34 @@ def test_model_hessian_lindh2007d3_vs_reference():
     print("Lindh2007D3 on the device vs the reference: worst deviation", worst)
 
 
+def test_model_hessian_ts_modifier_vs_reference():
+    """G10d: the `ts` modifier of ApproxHessian.main (tshess.py: reflection of the lowest non-zero mode of the model Hessian; eigen-solve on the
+    device) on top of fischerd3old and schlegel; where the reference indexes past the end (a model Hessian without any non-zero mode) the
+    class raises the same IndexError; `sr` and `ts` + `clip` raise NotImplementedError."""
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g10d_ts_modifier.npz"))
+    worst = 0.0
+    for tag in z["tags"]:
+        x, el = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]]
+        for model in ("fischerd3old", "schlegel"):
+            ref = z[f"{tag}_Hts_{model}"]
+            if ref.size == 0:
+                with pytest.raises(IndexError):
+                    ApproxHessian().main(x, el, np.zeros_like(x), approx_hess_type=model + "_ts")
+                continue
+            H = ApproxHessian().main(x, el, np.zeros_like(x), approx_hess_type=model + "_ts")
+            d = np.abs(H - ref).max()
+            worst = max(worst, d)
+            assert d < 1e-10 * max(1.0, np.abs(ref).max()), (tag, model, d)
+            w = np.linalg.eigvalsh(0.5 * (H + H.T))
+            assert w[0] < -1e-8                                       # one reflected mode
+    with pytest.raises(NotImplementedError):
+        ApproxHessian().main(z["co2_x"], ["C", "O", "O"], None, approx_hess_type="fischerd3old_sr")
+    with pytest.raises(NotImplementedError):
+        ApproxHessian().main(z["co2_x"], ["C", "O", "O"], None, approx_hess_type="fischerd3old_ts_clip")
+    print("ts modifier on the device vs the reference: worst deviation", worst)
+
+
 def test_model_hessian_large_cluster_vs_oracle():
     """100 and 200 atoms (argon: D3 pair terms only; a C/H chain: thousands of internal coordinates) against the oracle."""
     from oracle import model_hessian as mh
