@@ -335,6 +335,12 @@ int mopt_constraint_project_hess(mopt_ctx *ctx, int n, const double *H, int c, c
 int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
                      const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
                      const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym);
+/* The same with the null-space basis formed on the device (crsirfo.py:26-46 returns it from an SVD on the host): Qrows = r orthonormal rows
+ * (r x n, r <= 64) spanning the row space of the normalised constraint vectors; U = the last n - r columns of the Householder QR's orthogonal
+ * factor of Qrows^T.  The step, the predicted change and the trust-radius logic do not depend on the choice of basis inside the null space. */
+int mopt_crsirfo_run_rowspace(mopt_ctx *ctx, int n, int r, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
+                              const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                              const double *pre_g, const double *B_e, const double *Qrows, double *step, double *H_inplace, double *H_sym);
 
 /* ---- bias potentials ------------------------------------------------------------------------
  * AFIR (multioptpy/Potential/AFIR_potential.py:19-54): E = alpha A / B over the atom pairs of two fragments; the reference gets

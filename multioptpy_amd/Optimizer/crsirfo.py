@@ -2,13 +2,13 @@
 
 Host: the SHAKE-like coordinate correction (through the constraints object, in place -- the reference's gradient transport never
 fires for contiguous ndarray input because its displacement is taken after the in-place correction, crsirfo.py:62-83; kept as is),
-the null-space basis of the normalised constraint rows (the same LAPACK call as the reference: scipy.linalg.svd on the 3N x c
-matrix) and the convergence test on the projected gradient.  Device (``mopt_crsirfo_run``): Hessian update, U^T (H + bias) U on
-the FP64 matrix cores, the symmetric eigen-solve and the RS-I-RFO step in the subspace, step = U step_sub."""
+the rank and an orthonormal basis of the constraints' ROW space (c x c Gram matrix: O(c^2 n)) and the convergence test on the
+projected gradient.  Device (``mopt_crsirfo_run_rowspace``): the null-space basis U (Householder QR of the row space; it never crosses
+PCIe), Hessian update, U^T (H + bias) U on the FP64 matrix cores, the symmetric eigen-solve and the RS-I-RFO step in the subspace,
+step = U step_sub."""
 import ctypes as C
 
 import numpy as np
-import scipy.linalg
 
 from .rsirfo import RSIRFO
 from .._lib import lib, ctx, check, f64, ptr
@@ -22,22 +22,25 @@ class CRSIRFO(RSIRFO):
         self.svd_threshold = config.get("svd_threshold", 1e-5)
         self.proj_grad_converged = False
 
-    def _get_null_space_basis(self, geom):
+    def _row_space(self, geom):
+        """Orthonormal rows spanning the row space of the normalised constraint vectors, (r, n) -- r = 0: no active constraint.  The
+        reference takes the null space from the full SVD of the 3N x c matrix (crsirfo.py:26-46: singular values above
+        max(svd_threshold, 1e-6 S_max) count); the same rank follows from the c x c Gram matrix (its eigenvalues are the squared singular
+        values), and the null-space basis itself is formed on the device from these rows (mopt_crsirfo_run_rowspace)."""
         n = len(geom) * 3
         if self.constraints_obj is None:
-            return np.eye(n)
+            return np.zeros((0, n))
         B = self.constraints_obj._get_all_constraint_vectors(np.asarray(geom).reshape(-1, 3))
         if B is None or len(B) == 0:
-            return np.eye(n)
-        norms = np.linalg.norm(B, axis=1)
-        norms[norms < 1e-12] = 1.0
-        Bn = B / norms[:, None]
-        try:
-            U, S, _ = scipy.linalg.svd(Bn.T, full_matrices=True)
-        except np.linalg.LinAlgError:
-            return np.eye(n)
-        thr = max(self.svd_threshold, (S[0] if len(S) > 0 else 1.0) * 1e-6)
-        return U[:, int(np.sum(S > thr)):]
+            return np.zeros((0, n))
+        lengths = np.linalg.norm(B, axis=1)
+        Bn = B / np.where(lengths < 1e-12, 1.0, lengths)[:, None]
+        lam, W = np.linalg.eigh(Bn @ Bn.T)
+        sing = np.sqrt(np.clip(lam, 0.0, None))
+        keep = sing > max(self.svd_threshold, (sing.max() if sing.size else 1.0) * 1e-6)
+        if not np.any(keep):
+            return np.zeros((0, n))
+        return np.ascontiguousarray((W[:, keep].T @ Bn) / sing[keep][:, None])
 
     def run(self, geom_num_list, B_g, pre_B_g=[], pre_geom=[], B_e=0.0, pre_B_e=0.0, pre_move_vector=[], initial_geom_num_list=[], g=[], pre_g=[]):
         if self.Initialization:
@@ -67,12 +70,13 @@ class CRSIRFO(RSIRFO):
             geom_num_list = corrected.reshape(original_shape)
         x = f64(np.asarray(geom_num_list)).reshape(1, -1)
         n = x.shape[1]
-        U = self._get_null_space_basis(np.asarray(geom_num_list).reshape(-1, 3))
-        if U.shape[1] == 0:
+        Qc = self._row_space(np.asarray(geom_num_list).reshape(-1, 3))
+        if Qc.shape[0] >= n:
             return np.zeros_like(gradient_full).reshape(-1, 1)
         do_update = (self.prev_geometry is not None and self.prev_gradient is not None and len(pre_g) > 0 and len(pre_geom) > 0)
-        gradient_sub = U.T @ gradient_full
-        if np.linalg.norm(gradient_sub) < self.gradient_norm_threshold and not do_update:
+        # |U^T g| = |g - Qc^T Qc g| for any orthonormal basis U of the complement
+        gsub_norm = float(np.linalg.norm(gradient_full - Qc.T @ (Qc @ gradient_full)))
+        if gsub_norm < self.gradient_norm_threshold and not do_update:
             # crsirfo.py:116-125 (with a pending Hessian update the device call below performs it first, as the reference does, and the
             # test is repeated afterwards)
             self.proj_grad_converged = True
@@ -94,11 +98,11 @@ class CRSIRFO(RSIRFO):
         Hsym = np.empty((n, n)) if do_update else None
         p = self._params()
         s = self._state()
-        Uc = f64(U)
+        Qd = f64(Qc) if Qc.shape[0] > 0 else None
         c = ctx(self.device)
-        check(lib().mopt_crsirfo_run(c, n, U.shape[1], C.byref(p), C.byref(s), ptr(f64(H)), ptr(Bh), ptr(x), ptr(bg), ptr(graw), ptr(px), ptr(pg),
-                                     ptr(be), ptr(Uc), ptr(step), ptr(Hin), ptr(Hsym)), c)
-        converged_now = np.linalg.norm(gradient_sub) < self.gradient_norm_threshold
+        check(lib().mopt_crsirfo_run_rowspace(c, n, Qc.shape[0], C.byref(p), C.byref(s), ptr(f64(H)), ptr(Bh), ptr(x), ptr(bg), ptr(graw), ptr(px), ptr(pg),
+                                              ptr(be), ptr(Qd), ptr(step), ptr(Hin), ptr(Hsym)), c)
+        converged_now = gsub_norm < self.gradient_norm_threshold
         if do_update and s.hess_updated:
             H[...] = Hin if H.dtype == np.float64 else Hin.astype(H.dtype)
             self.hessian = Hsym

@@ -79,6 +79,8 @@ def _proto(lib):
         lib.mopt_constraint_project_hess.argtypes = [vp, C.c_int, DP, C.c_int, DP, C.c_int, DP, C.c_double, C.c_double, DP]
         lib.mopt_crsirfo_run.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),
                                          DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
+        lib.mopt_crsirfo_run_rowspace.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),
+                                         DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_keep_pot"):
         lib.mopt_keep_pot.argtypes = [vp, C.c_int, DP, C.c_int, IP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_afir"):

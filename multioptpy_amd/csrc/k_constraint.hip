@@ -75,6 +75,67 @@ __global__ void __launch_bounds__(256) k_pad_copy(int m, int n, const double *__
     if (i < n) dst[i] = (i < m) ? src[i] : 0.0;
 }
 
+
+// ---- null-space basis of the constraints on the device (round 3) -------------------------------------------------------------------
+// Input: r orthonormal rows spanning the constraints' row space (Y: r x n, overwritten).  k_rowspace_qr: Householder QR (dgeqr2
+// conventions) of the n x r matrix whose column k is row k of Y -- reflector k stays in Y[k][k + 1 ..] (v[k] = 1 implied), tau[k].
+// k_nullspace_fill: column j of U = H_0 ... H_{r-1} e_{r+j} (the last n - r columns of the orthogonal factor), written into the padded
+// n x n array Up (U in its first n - r columns) -- one thread per column, the reflectors applied in place; k_transpose_sq makes Up^T.
+// One workgroup / a few dozen: O(n r^2) and O(n (n - r) r) flops, nothing that crosses PCIe but the r x n rows.
+__global__ void __launch_bounds__(256) k_rowspace_qr(int n, int r, double *__restrict__ Y, double *__restrict__ tau) {
+    __shared__ double red[16];
+    __shared__ double s_tau;
+    for (int k = 0; k < r; ++k) {
+        double *col = Y + (size_t)k * n;
+        double nn = 0.0;
+        for (int i = k + 1 + threadIdx.x; i < n; i += blockDim.x) nn += col[i] * col[i];
+        nn = block_sum1(nn, red);
+        const double xnorm = sqrt(nn), alpha = col[k];
+        __syncthreads();
+        double t = 0.0;
+        if (xnorm != 0.0) {
+            const double beta = -copysign(hypot(alpha, xnorm), alpha);
+            t = (beta - alpha) / beta;
+            const double scal = 1.0 / (alpha - beta);
+            for (int i = k + 1 + threadIdx.x; i < n; i += blockDim.x) col[i] *= scal;
+        }
+        if (threadIdx.x == 0) { s_tau = t; tau[k] = t; }
+        __syncthreads();
+        if (t != 0.0) {
+            for (int c = k + 1; c < r; ++c) {
+                double *cc = Y + (size_t)c * n;
+                double d = 0.0;
+                for (int i = k + threadIdx.x; i < n; i += blockDim.x) d += (i == k ? 1.0 : col[i]) * cc[i];
+                d = block_sum1(d, red);
+                for (int i = k + threadIdx.x; i < n; i += blockDim.x) cc[i] -= t * (i == k ? 1.0 : col[i]) * d;
+                __syncthreads();
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) k_nullspace_fill(int n, int r, const double *__restrict__ Y, const double *__restrict__ tau, double *__restrict__ Up) {
+    const int j = blockIdx.x * 256 + threadIdx.x, m = n - r;
+    if (j >= m) return;
+    for (int i = 0; i < n; ++i) Up[(size_t)i * n + j] = (i == r + j) ? 1.0 : 0.0;
+    for (int k = r - 1; k >= 0; --k) {
+        const double t = tau[k];
+        if (t == 0.0) continue;
+        const double *v = Y + (size_t)k * n;
+        double d = Up[(size_t)k * n + j];
+        for (int i = k + 1; i < n; ++i) d += v[i] * Up[(size_t)i * n + j];
+        d *= t;
+        Up[(size_t)k * n + j] -= d;
+        for (int i = k + 1; i < n; ++i) Up[(size_t)i * n + j] -= d * v[i];
+    }
+}
+__global__ void __launch_bounds__(256) k_transpose_sq(int n, const double *__restrict__ A, double *__restrict__ At) {
+    __shared__ double T[16][17];
+    const int bx = blockIdx.x * 16, by = blockIdx.y * 16, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    if (by + ty < n && bx + tx < n) T[ty][tx] = A[(size_t)(by + ty) * n + bx + tx];
+    __syncthreads();
+    if (bx + ty < n && by + tx < n) At[(size_t)(bx + ty) * n + by + tx] = T[tx][ty];
+}
+
 }  // namespace mopt
 
 namespace {
@@ -120,7 +181,7 @@ extern "C" int mopt_constraint_project_hess(mopt_ctx *ctx, int n, const double *
 // B_g is the full-space gradient (after the caller's gradient transport, if any).
 static int crsirfo_run_once(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
                             const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
-                            const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym);
+                            const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym, const double *Qrows = nullptr);
 
 extern "C" int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
                                 const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
@@ -143,12 +204,37 @@ extern "C" int mopt_crsirfo_run(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_p
     return rc;
 }
 
+
+// The same with the null-space basis formed on the device: Qrows = r orthonormal rows (r x n) spanning the row space of the constraints
+// (r <= 64); the step lives in their orthogonal complement (m = n - r columns).
+extern "C" int mopt_crsirfo_run_rowspace(mopt_ctx *ctx, int n, int r, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
+                                         const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
+                                         const double *pre_g, const double *B_e, const double *Qrows, double *step, double *H_inplace, double *H_sym) {
+    if (!ctx || !state) return MOPT_E_ARG;
+    if (r < 0 || r > 64 || r >= n || (r > 0 && !Qrows)) { ctx->err = "mopt_crsirfo_run_rowspace: bad row space"; return MOPT_E_ARG; }
+    static const double dummy = 0.0;
+    const double *Q = r > 0 ? Qrows : &dummy;
+    const mopt_rsirfo_state st0 = *state;
+    std::vector<double> hkeep;
+    if (hessian && n > 0 && (H_inplace == hessian || H_sym == hessian)) hkeep.assign(hessian, hessian + (size_t)n * n);
+    int rc = crsirfo_run_once(ctx, n, n - r, params, state, hessian, bias_hessian, geom, B_g, g, pre_geom, pre_g, B_e, nullptr, step, H_inplace, H_sym, Q);
+    if (rc == MOPT_E_NUMERIC && state->jacobi_sweeps == -2) {
+        *state = st0;
+        const bool saved = ctx->tri_no_persist;
+        ctx->tri_no_persist = true;
+        rc = crsirfo_run_once(ctx, n, n - r, params, state, hkeep.empty() ? hessian : hkeep.data(), bias_hessian, geom, B_g, g, pre_geom, pre_g, B_e, nullptr,
+                              step, H_inplace, H_sym, Q);
+        ctx->tri_no_persist = saved;
+    }
+    return rc;
+}
+
 static int crsirfo_run_once(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_params *params, mopt_rsirfo_state *state, const double *hessian,
                             const double *bias_hessian, const double *geom, const double *B_g, const double *g, const double *pre_geom,
-                            const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym) {
+                            const double *pre_g, const double *B_e, const double *U, double *step, double *H_inplace, double *H_sym, const double *Qrows) {
     using namespace mopt;
     if (!ctx) return MOPT_E_ARG;
-    if (n < 1 || n > MOPT_MAX_N || m < 1 || m > n || !params || !state || !geom || !B_g || !B_e || !U || !step) { ctx->err = "mopt_crsirfo_run: bad arguments"; return MOPT_E_ARG; }
+    if (n < 1 || n > MOPT_MAX_N || m < 1 || m > n || !params || !state || !geom || !B_g || !B_e || (!U && !Qrows) || !step) { ctx->err = "mopt_crsirfo_run: bad arguments"; return MOPT_E_ARG; }
     if (!hessian) { ctx->err = "Hessian matrix must be set before running optimization"; return MOPT_E_STATE; }
     hipSetDevice(ctx->device);
     RsirfoWork wk, ws;
@@ -167,11 +253,25 @@ static int crsirfo_run_once(mopt_ctx *ctx, int n, int m, const mopt_rsirfo_param
     CH2D(ctx, ws.params, params, sizeof(mopt_rsirfo_params)); CH2D(ctx, ws.states, state, sizeof(mopt_rsirfo_state));
     CH2D(ctx, ws.be, B_e, 8);
     // padded basis: Upad (n x n, U in its first m columns) and its transpose
-    std::vector<double> up((size_t)n * n, 0.0), upt((size_t)n * n, 0.0);
-    for (int i = 0; i < n; ++i) for (int k = 0; k < m; ++k) { const double v = U[(size_t)i * m + k]; up[(size_t)i * n + k] = v; upt[(size_t)k * n + i] = v; }
-    DB dU, dUt, dvec;
+    DB dU, dUt, dvec, dY;
     CTRY_(dU.alloc(ctx, nn)); CTRY_(dUt.alloc(ctx, nn)); CTRY_(dvec.alloc(ctx, 2 * nv));
-    CH2D(ctx, dU.p, up.data(), nn); CH2D(ctx, dUt.p, upt.data(), nn);
+    std::vector<double> up, upt;
+    if (Qrows) {
+        // from the r = n - m orthonormal rows of the constraints' row space, on the device: only r x n numbers cross PCIe
+        const int r = n - m;
+        CTRY_(dY.alloc(ctx, (size_t)(r > 0 ? r : 1) * n * 8 + 64 * 8));
+        double *Y = dY.as<double>(), *tauv = Y + (size_t)(r > 0 ? r : 1) * n;
+        if (r > 0) CH2D(ctx, Y, Qrows, (size_t)r * n * 8);
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(dU.p, 0, nn, ctx->stream));
+        mopt_scope sc(ctx, "constraint", 3);
+        if (r > 0) hipLaunchKernelGGL(k_rowspace_qr, dim3(1), dim3(256), 0, ctx->stream, n, r, Y, tauv);
+        hipLaunchKernelGGL(k_nullspace_fill, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, n, r, (const double *)Y, (const double *)tauv, dU.as<double>());
+        hipLaunchKernelGGL(k_transpose_sq, dim3((n + 15) / 16, (n + 15) / 16), dim3(256), 0, ctx->stream, n, (const double *)dU.as<double>(), dUt.as<double>());
+    } else {
+        up.assign((size_t)n * n, 0.0); upt.assign((size_t)n * n, 0.0);
+        for (int i = 0; i < n; ++i) for (int k = 0; k < m; ++k) { const double v = U[(size_t)i * m + k]; up[(size_t)i * n + k] = v; upt[(size_t)k * n + i] = v; }
+        CH2D(ctx, dU.p, up.data(), nn); CH2D(ctx, dUt.p, upt.data(), nn);
+    }
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));       // (the staging vectors go out of use below)
     const UpdateCoef *coef = nullptr;
     if (upd) {

@@ -690,6 +690,41 @@ def test_constraint_kinds_fbond_rot_eigvec_atoms_pair_vs_reference():
     tog._check_g12b(z, lambda names, atoms: ProjectOutConstrain(names, atoms), lambda pc, x: pc._get_all_constraint_vectors(x), 1e-8)
 
 
+def test_crsirfo_device_null_space_matches_host_basis():
+    """mopt_crsirfo_run_rowspace (null-space basis by Householder QR on the device, from r orthonormal rows) against mopt_crsirfo_run with a
+    null-space basis from the host's SVD: the step, the state and the updated Hessians do not depend on the basis inside the null space."""
+    import ctypes as C
+    import scipy.linalg
+    from multioptpy_amd import _lib
+    from multioptpy_amd._lib import f64, ptr
+    from multioptpy_amd.Optimizer.crsirfo import CRSIRFO
+    rng = np.random.default_rng(77)
+    for N, r in ((7, 2), (22, 5), (40, 9)):
+        n = 3 * N
+        x = cases.cluster(N, jitter=0.1)
+        E, G = cases.lj(x)
+        H = cases.lj(x, hessian=True)[2] + 0.3 * np.eye(n)
+        Qc = np.linalg.qr(rng.normal(size=(n, r)))[0].T.copy()
+        U = scipy.linalg.null_space(Qc)
+        opt = CRSIRFO(constraints=None, method="rsirfo_fsb", saddle_order=0)
+        outs = []
+        for form in ("host", "device"):
+            p, st = opt._params(), opt._state()
+            step = np.empty((1, n))
+            c = _lib.ctx(None)
+            args = (C.byref(p), C.byref(st), ptr(f64(H)), None, ptr(f64(x.reshape(1, -1))), ptr(f64(G.reshape(1, -1))), ptr(f64(G.reshape(1, -1))), None, None,
+                    ptr(np.array([E])))
+            if form == "host":
+                _lib.check(_lib.lib().mopt_crsirfo_run(c, n, n - r, *args, ptr(f64(U)), ptr(step), None, None), c)
+            else:
+                _lib.check(_lib.lib().mopt_crsirfo_run_rowspace(c, n, r, *args, ptr(f64(Qc)), ptr(step), None, None), c)
+            outs.append((step.copy(), float(st.trust_radius), float(st.predicted[0])))
+        d = np.abs(outs[0][0] - outs[1][0]).max()
+        assert d < 1e-10, (N, r, d)
+        assert abs(outs[0][2] - outs[1][2]) < 1e-12 * max(1.0, abs(outs[0][2]))
+        assert np.abs(Qc @ outs[1][0].ravel()).max() < 1e-12                      # the step stays in the complement of the row space
+
+
 def test_crsirfo_traces_vs_reference():
     """G12: three consecutive CRSIRFO.run calls (bond + angle constraints, SHAKE-like correction, subspace RFO) against the reference:
     step (<= 1e-8), trust radius, updated Hessian."""
