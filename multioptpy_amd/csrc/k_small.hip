@@ -632,6 +632,10 @@ __global__ void __launch_bounds__(1024) k_small_rsprfo(SmallPrfoArgs a) {
     const int rule = a.params[0].rule;
     const bool flow = rule == MOPT_RULE_FLOWCHART;
     constexpr int EPT = 6;
+    long long stamp[8];
+    int nst = 0;
+#define SP_STAMP() do { if (a.dbg && tid == 0) stamp[nst] = wall_clock64(); ++nst; } while (0)
+    SP_STAMP();
 
     for (int i = tid; i < n; i += 1024) {
         sx[i] = a.x[i]; sbg[i] = a.bg[i];
@@ -649,6 +653,7 @@ __global__ void __launch_bounds__(1024) k_small_rsprfo(SmallPrfoArgs a) {
     }
     lds_barrier();
     int updated = 0;
+    SP_STAMP();
     // ================= 1. previous step
     if (a.has_prev_step) {
         for (int e = tid; e < nn; e += 1024) M2[e] = M[e];
@@ -675,6 +680,7 @@ __global__ void __launch_bounds__(1024) k_small_rsprfo(SmallPrfoArgs a) {
         }
         lds_barrier();
     }
+    SP_STAMP();
     // ================= 2. checked update with y = B_g - pre_B_g
     if (a.do_update) {
         const int grp = tid >> 4, l = tid & 15;
@@ -743,11 +749,13 @@ __global__ void __launch_bounds__(1024) k_small_rsprfo(SmallPrfoArgs a) {
             lds_barrier();
         }
     }
+    SP_STAMP();
     // ================= 3./4. A = sym(H + bias), eigen-decomposition, g~, overlaps
     small_sym_project(n, M, a.Bias, sQ, sW6, sM6, false);
     const int noeig = small_eigen<CH>(n, 0, M, aux, R1, sD, sE, sTAU, sWT, sW, sperm, sbs, sbe, seinfo, a.A, a.Zt, s_einfo_g, a.sticky, sgp, sgt,
                                       a.have_ts ? sts : nullptr, sov);
     double *sV = R1 + nn;
+    SP_STAMP();
     // ================= 5. scalar stage
     if (wid == 0) {
         if (lane == 0) s_st.gradient_norm = s_gn;
@@ -755,6 +763,11 @@ __global__ void __launch_bounds__(1024) k_small_rsprfo(SmallPrfoArgs a) {
         prfo_scalar_body<true>(n, a.params, &s_st, sW, sperm, seinfo, sgt, sov, a.have_ts, scf, &s_tsrow, R1 + 2 * nn);
     }
     lds_barrier();
+    SP_STAMP();
+    if (a.dbg && tid == 0)
+        printf("[small-prfo] n=%d: load %.1f, previous step %.1f, update %.1f, eigen %.1f, scalar %.1f us\n", n, (stamp[1] - stamp[0]) * 0.01, (stamp[2] - stamp[1]) * 0.01,
+               (stamp[3] - stamp[2]) * 0.01, (stamp[4] - stamp[3]) * 0.01, (stamp[5] - stamp[4]) * 0.01);
+#undef SP_STAMP
     if (tid < n) {
         double out;
         if (noeig) out = -scf[tid];
@@ -857,7 +870,8 @@ int mopt_launch_small_rsprfo(mopt_ctx *ctx, RsirfoWork &wk, const SmallPrfoIO &i
     const int n = io.n;
     if (!mopt_small_eligible(n)) { ctx->err = "mopt_launch_small_rsprfo: n out of range"; return MOPT_E_ARG; }
     SmallPrfoArgs a;
-    a.n = n; a.has_prev_step = io.has_prev_step; a.do_update = io.do_update; a.have_ts = io.have_ts; a.dbg = 0;
+    static const int pdbg = getenv("MOPT_SMALL_DBG") ? 1 : 0;
+    a.n = n; a.has_prev_step = io.has_prev_step; a.do_update = io.do_update; a.have_ts = io.have_ts; a.dbg = pdbg;
     a.B_e = io.B_e; a.pre_move_norm = io.pre_move_norm;
     a.params = io.params; a.state = io.state;
     a.x = io.x; a.bg = io.bg; a.px = io.px; a.pg = io.pg; a.prevg = io.prevg; a.prevs = io.prevs; a.ts = io.ts; a.Hin = io.Hin; a.Bias = io.Bias;

@@ -42,6 +42,13 @@ template <class R>
 __device__ inline double arrow_extreme(const R &red, const double *lam, const double *g, const int *idx, int m, double alpha,
                                        bool maximise, double *sd, double *sb2) {
     const double sg = maximise ? -1.0 : 1.0;      // largest root of (D, b) = - smallest root of (-D, b)
+    if (m == 1) {
+        // one pole (the usual maximisation subspace of a first-order saddle search): mu^2 - D mu - b^2 = 0 in closed form, written so that
+        // no cancellation occurs for either sign of D
+        const double D = sg * lam[idx[0]] / alpha, b = g[idx[0]] / alpha, rt = sqrt(D * D + 4.0 * b * b);
+        const double mu = (D > 0.0) ? -2.0 * b * b / (D + rt) : 0.5 * (D - rt);
+        return sg * mu;
+    }
     double dmin_ = INFINITY, bbl = 0.0;
     for (int k = threadIdx.x & 63; k < m; k += WAVE) {
         const double d = sg * lam[idx[k]] / alpha, b = g[idx[k]] / alpha;
