@@ -10,35 +10,11 @@
 
 #include "pipeline.h"
 #include "neb_tr.hpp"
+#include "neb_gamma.hpp"
 
 namespace mopt {
 
 constexpr double BOHR2ANG = 0.52917721067;     // neb.py:201
-
-// 6x6 solve by LU with partial pivoting (numpy.linalg.solve = dgesv); returns false on an exactly zero pivot.
-__device__ inline bool solve6(double A[6][6], double b[6]) {
-    for (int k = 0; k < 6; ++k) {
-        int p = k;
-        double mx = fabs(A[k][k]);
-        for (int r = k + 1; r < 6; ++r) if (fabs(A[r][k]) > mx) { mx = fabs(A[r][k]); p = r; }
-        if (A[p][k] == 0.0) return false;
-        if (p != k) {
-            for (int c = 0; c < 6; ++c) { double t = A[k][c]; A[k][c] = A[p][c]; A[p][c] = t; }
-            double t = b[k]; b[k] = b[p]; b[p] = t;
-        }
-        for (int r = k + 1; r < 6; ++r) {
-            const double f = A[r][k] / A[k][k];
-            for (int c = k; c < 6; ++c) A[r][c] -= f * A[k][c];
-            b[r] -= f * b[k];
-        }
-    }
-    for (int k = 5; k >= 0; --k) {
-        double s = b[k];
-        for (int c = k + 1; c < 6; ++c) s -= A[k][c] * b[c];
-        b[k] = s / A[k][k];
-    }
-    return true;
-}
 
 // band inputs of a step handed over in device memory: X, G (I n doubles each) and E (I doubles)
 __global__ void __launch_bounds__(256) k_band_take(int nd, int I, const double *__restrict__ sX, const double *__restrict__ sG,
@@ -78,31 +54,10 @@ __global__ void __launch_bounds__(256) k_gamma(int I, int n, int first, const do
     const double *xm = X + (size_t)(i - 1) * n, *x0 = X + (size_t)i * n, *xp = X + (size_t)(i + 1) * n;
     const double *gm = G + (size_t)(i - 1) * n, *g0 = G + (size_t)i * n, *gp = G + (size_t)(i + 1) * n;
     const double *t = tau + (size_t)i * n;
-    double v[5] = {0, 0, 0, 0, 0};
-    for (int k = threadIdx.x; k < n; k += blockDim.x) {
-        const double dm = x0[k] - xm[k], dp = xp[k] - x0[k];
-        v[0] += dm * dm; v[1] += dp * dp; v[2] += gm[k] * dm; v[3] += g0[k] * t[k]; v[4] += gp[k] * dp;
-    }
+    double v[5];
+    ayala_partial_sums(n, xm, x0, xp, gm, g0, gp, t, v);
     block_sum<5>(v, red);
-    if (threadIdx.x == 0) {
-        const double dprev = sqrt(v[0]), dnext = sqrt(v[1]);
-        double gam = 0.0;
-        if (!(dprev < 1e-6 || dnext < 1e-6)) {
-            const double s[3] = {-dprev, 0.0, dnext};
-            double A[6][6], b[6];
-            for (int r = 0; r < 3; ++r) {
-                double pw = 1.0;
-                for (int c = 0; c < 6; ++c) { A[r][c] = pw; pw *= s[r]; }
-                A[3 + r][0] = 0.0;
-                pw = 1.0;
-                for (int c = 1; c < 6; ++c) { A[3 + r][c] = c * pw; pw *= s[r]; }
-            }
-            b[0] = E[i - 1]; b[1] = E[i]; b[2] = E[i + 1];
-            b[3] = v[2] / dprev; b[4] = v[3]; b[5] = v[4] / dnext;
-            if (solve6(A, b)) gam = 2.0 * b[2];
-        }
-        gamma[loc] = gam;
-    }
+    if (threadIdx.x == 0) gamma[loc] = ayala_gamma(v[0], v[1], v[2], v[3], v[4], E[i - 1], E[i], E[i + 1]);
 }
 
 // H[loc] += gamma[loc] * t t^T      grid (ceil(n/8), owned), block 256: 8 rows per block, 32 lanes per row
@@ -517,7 +472,8 @@ int mopt_band_step_phase_a(mopt_band *b, int optimize_num) {
     // 1. NEB force.  Whole band on one device: all images (FIRE's switch sums over all of F).  Image-sharded: the owned images;
     //    the switch is assembled from per-rank partial sums.
     if (!sharded) {
-        BTRY(mopt_launch_bneb_force(ctx, I, N, 0, I, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau));
+        // (gamma of the owned images comes out of the same launch when this band owns them all: gamma[] is indexed by the local image)
+        BTRY(mopt_launch_bneb_force(ctx, I, N, 0, I, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau, (first == 0 && count == I) ? b->gamma : nullptr));
     } else {
         BTRY(mopt_launch_bneb_force(ctx, I, N, first, count, b->X, b->E, b->G, optimize_num > b->apply_ci ? 1 : 0, b->F, b->tau));
         if (have_prev) {
@@ -607,7 +563,10 @@ int mopt_band_step_phase_b(mopt_band *b, int optimize_num) {
     const bool fused = b->fused_step;
     {
         mopt_scope sc(ctx, "neb_ayala", fused ? 1 : 2);
-        hipLaunchKernelGGL(k_gamma, dim3(count), dim3(256), 0, ctx->stream, I, n, first, b->X, b->E, b->G, b->tau, b->gamma);
+        // (since round 3 the force kernel of phase a leaves gamma behind: MOPT_BAND_GAMMA_KERNEL=1 restores the separate launch)
+        // bands that own only a part of the images keep the launch (the force kernel above runs over all images or before the halo is complete)
+        static const bool own_kernel = getenv("MOPT_BAND_GAMMA_KERNEL") && atoi(getenv("MOPT_BAND_GAMMA_KERNEL")) == 1;
+        if (own_kernel || sharded || !(first == 0 && count == I)) hipLaunchKernelGGL(k_gamma, dim3(count), dim3(128) /* the force kernel's block: same summation order, bitwise the same gamma */, 0, ctx->stream, I, n, first, b->X, b->E, b->G, b->tau, b->gamma);
         if (!fused) hipLaunchKernelGGL(k_rank1, dim3((n + 7) / 8, count), dim3(256), 0, ctx->stream, n, first, b->gamma, b->tau, wk.H);
     }
     const mopt::FusedBand fb = {b->gamma, b->tau, first, have_prev ? 1 : 0, false};

@@ -8,6 +8,7 @@
 //   k_neb_post     step limit (rfo_neb.py:76-83), TR_calc (trust_radius_neb.py:17-98), FIRE (fire_neb.py:38-92),
 //                  blend (rfo_neb.py:197-206)
 #include "common.hpp"
+#include "neb_gamma.hpp"
 
 namespace mopt {
 
@@ -28,13 +29,17 @@ __device__ __forceinline__ void proj_atom(const double *xa, const double *xb, co
 // X, G: [Iglob][N][3]; E: [Iglob]; images [first, first+count) are computed (image-sharded band).
 __global__ void __launch_bounds__(128) k_bneb_force(int I, int N, int first, const double *__restrict__ X,
                                                     const double *__restrict__ E, const double *__restrict__ G,
-                                                    int ci_active, double *__restrict__ F, double *__restrict__ tau) {
+                                                    int ci_active, double *__restrict__ F, double *__restrict__ tau, double *__restrict__ gamma) {
+    // gamma != null: the Ayala curvature of the image (gamma[blockIdx.x]; 0 for the end images) is left behind as well -- the band step needs it
+    // right after the force and a launch of its own cost 8 us of a 0.2 ms step (16 x 14)
+    __shared__ double red[5 * 16];
     const int i = first + blockIdx.x;
     const size_t off = (size_t)i * N * 3;
     const double *g = G + off;
     double *f = F + off, *tg = tau + off;
     if (i == 0 || i == I - 1) {
         for (int k = threadIdx.x; k < 3 * N; k += blockDim.x) { f[k] = -1.0 * g[k]; tg[k] = 0.0; }
+        if (gamma && threadIdx.x == 0) gamma[blockIdx.x] = 0.0;
         return;
     }
     const double *xm = X + off - (size_t)N * 3, *x0 = X + off, *xp = X + off + (size_t)N * 3;
@@ -65,6 +70,14 @@ __global__ void __launch_bounds__(128) k_bneb_force(int I, int N, int first, con
             f[3 * a + c] = -1.0 * force;
             tg[3 * a + c] = t[c];
         }
+    }
+    if (gamma) {
+        __syncthreads();                                      // (the tangent written above, read back by other threads of the workgroup)
+        const double *gm = G + off - (size_t)N * 3, *gp = G + off + (size_t)N * 3;
+        double v[5];
+        ayala_partial_sums(3 * N, xm, x0, xp, gm, g, gp, tg, v);
+        block_sum<5>(v, red);
+        if (threadIdx.x == 0) gamma[blockIdx.x] = ayala_gamma(v[0], v[1], v[2], v[3], v[4], e0, e1, e2);
     }
 }
 
@@ -249,10 +262,10 @@ int mopt_launch_neb_force_var(mopt_ctx *ctx, int variant, int I, int N, int firs
 }
 
 int mopt_launch_bneb_force(mopt_ctx *ctx, int I, int N, int first, int count, const double *d_X, const double *d_E,
-                           const double *d_G, int ci_active, double *d_F, double *d_tau) {
+                           const double *d_G, int ci_active, double *d_F, double *d_tau, double *d_gamma) {
     using namespace mopt;
     mopt_scope sc(ctx, "neb_force", 1);
-    hipLaunchKernelGGL(k_bneb_force, dim3(count), dim3(128), 0, ctx->stream, I, N, first, d_X, d_E, d_G, ci_active, d_F, d_tau);
+    hipLaunchKernelGGL(k_bneb_force, dim3(count), dim3(128), 0, ctx->stream, I, N, first, d_X, d_E, d_G, ci_active, d_F, d_tau, d_gamma);
     MOPT_HIP_TRY(ctx, hipGetLastError());
     return MOPT_OK;
 }

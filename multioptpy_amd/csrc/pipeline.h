@@ -172,4 +172,4 @@ int mopt_launch_neb_force_var(mopt_ctx *ctx, int variant, int I, int N, int firs
                               const double *d_G, int ci_active, double *d_F);
 int mopt_launch_norm_inf(mopt_ctx *ctx, int n, int batch, const double *d_A, double *d_sigma);   // sigma = 1.0625 * ||A||_inf
 int mopt_launch_bneb_force(mopt_ctx *ctx, int I, int N, int first, int count, const double *d_X, const double *d_E,
-                           const double *d_G, int ci_active, double *d_F, double *d_tau);
+                           const double *d_G, int ci_active, double *d_F, double *d_tau, double *d_gamma = nullptr);
