@@ -47,6 +47,16 @@ __global__ void k_norm1(int n, const double *__restrict__ v, double *__restrict_
 }
 
 __global__ void k_set_gnorm(mopt_rsprfo_state *st, const double *gn) { st[0].gradient_norm = gn[0]; }
+// outcome of the checked update (rsprfo.py:1236-1250) without a host round trip: flag = 0 no update applied, 1 accepted (the bound
+// ||candidate||_inf / 1.0625 <= 1e6 holds, so max |eig| <= 1e6 does too), 2 the spectrum itself has to be looked at (the caller repeats
+// the call through the path that does)
+__global__ void k_prfo_accept(const UpdateCoef *__restrict__ coef, const double *__restrict__ sigma, int *__restrict__ flag) {
+    flag[0] = coef[0].applied ? ((sigma[0] / 1.0625 <= 1e6) ? 1 : 2) : 0;
+}
+__global__ void __launch_bounds__(256) k_copy_if(size_t count, const int *__restrict__ flag, int want, const double *__restrict__ src, double *__restrict__ dst) {
+    if (flag[0] != want) return;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 // the tracked TS eigenvector (row *row of Vt; the unit vector when the solver fell back to the identity eigen-system) into a fixed buffer,
 // so that it travels with the other results instead of behind a second synchronisation
 __global__ void __launch_bounds__(256) k_prfo_tsrow(int n, const double *__restrict__ Vt, const int *__restrict__ row, const int *__restrict__ einfo, double *__restrict__ out) {
@@ -163,6 +173,117 @@ static int rsprfo_run_small(mopt_ctx *ctx, int n, const mopt_rsprfo_params *para
     return MOPT_OK;
 }
 
+
+int mopt_ws_get(mopt_ctx *ctx, int n, bool bias, size_t io_bytes, RsirfoWork **wk_out, void **io_out);      // mopt_abi.hip
+
+// The general path without its per-call allocations and without the synchronisation in the middle (round 3): cached workspace, the small
+// inputs through the pinned span in one copy, the accept / reject decision of the checked update taken on the device (k_prfo_accept); only the
+// rare case that needs the candidate's spectrum (flag 2) goes back to rsprfo_run_once.  n = 300: 2.07 -> see DESIGN section 6.
+static int rsprfo_run_fast(mopt_ctx *ctx, int n, const mopt_rsprfo_params *params, mopt_rsprfo_state *state, const double *hessian,
+                           const double *bias_hessian, const double *geom, const double *B_g, const double *pre_geom, const double *pre_B_g, double B_e,
+                           const double *prev_gradient, const double *prev_move_vector, double pre_move_norm, const double *ts_vec, double *step,
+                           double *H_out, double *ts_vec_out, bool *timed_out, bool *fallback) {
+    *timed_out = false; *fallback = false;
+    hipSetDevice(ctx->device);
+    const size_t nn = (size_t)n * n * 8, nv = (size_t)n * 8;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    // device span: [x | bg | px | pg | prevg | prevs | ts | par | st | rule | one]  then  [ov | tsrow | gn | flag]  then out [step | st | tsrow | bad | flag | tsout]
+    size_t off = 0;
+    auto take = [&](size_t b) { const size_t o = off; off += al(b); return o; };
+    const size_t o_x = take(nv), o_bg = take(nv), o_px = take(nv), o_pg = take(nv), o_prevg = take(nv), o_prevs = take(nv), o_ts = take(nv),
+                 o_par = take(sizeof(mopt_rsprfo_params)), o_st = take(sizeof(mopt_rsprfo_state)), o_rule = take(8), o_one = take(8), in_bytes = off,
+                 o_ov = take(nv), o_tsrow = take(16), o_gn = take(16), o_flag = take(16);
+    RsirfoWork *wkp = nullptr;
+    void *io = nullptr;
+    PTRY(mopt_ws_get(ctx, n, bias_hessian != nullptr, off, &wkp, &io));
+    RsirfoWork &wk = *wkp;
+    char *dio = (char *)io;
+    const bool stage_H = nn <= ((size_t)1 << 20);
+    const size_t p_out = al(in_bytes), p_st = p_out + al(nv), p_row = p_st + al(sizeof(mopt_rsprfo_state)), p_bad = p_row + 256, p_flag = p_bad + 256,
+                 p_ts = p_flag + 256, p_H = p_ts + al(nv);
+    char *pin = (char *)mopt_pin_get(ctx, p_H + (stage_H ? nn : 0));
+    if (!pin) { ctx->err = "hipHostMalloc failed (staging buffer)"; return MOPT_E_NOMEM; }
+    mopt_rsprfo_state st = *state;
+    st.last_ratio = NAN; st.last_actual = NAN; st.step_accepted = 1; st.hess_updated = 0;
+    const bool do_prev = st.has_prev && prev_gradient && prev_move_vector, do_upd = pre_geom && pre_B_g;
+    const int have_ts = (ts_vec != nullptr && st.ts_mode_idx >= 0) ? 1 : 0, rule = params->rule, one = 1;
+    std::memcpy(pin + o_x, geom, nv); std::memcpy(pin + o_bg, B_g, nv);
+    if (do_upd) { std::memcpy(pin + o_px, pre_geom, nv); std::memcpy(pin + o_pg, pre_B_g, nv); }
+    if (do_prev) { std::memcpy(pin + o_prevg, prev_gradient, nv); std::memcpy(pin + o_prevs, prev_move_vector, nv); }
+    if (have_ts) std::memcpy(pin + o_ts, ts_vec, nv);
+    std::memcpy(pin + o_par, params, sizeof(mopt_rsprfo_params)); std::memcpy(pin + o_st, &st, sizeof(st));
+    std::memcpy(pin + o_rule, &rule, sizeof(int)); std::memcpy(pin + o_one, &one, sizeof(int));
+    PH2D(dio, pin, in_bytes);
+    PH2D(wk.H, hessian, nn);
+    if (bias_hessian) PH2D(wk.Bias, bias_hessian, nn);
+    double *dx = (double *)(dio + o_x), *dbg = (double *)(dio + o_bg), *dpx = (double *)(dio + o_px), *dpg = (double *)(dio + o_pg),
+           *dprevg = (double *)(dio + o_prevg), *dprevs = (double *)(dio + o_prevs), *dts = (double *)(dio + o_ts), *dov = (double *)(dio + o_ov),
+           *dgn = (double *)(dio + o_gn);
+    mopt_rsprfo_params *dpar = (mopt_rsprfo_params *)(dio + o_par);
+    mopt_rsprfo_state *dst = (mopt_rsprfo_state *)(dio + o_st);
+    int *drule = (int *)(dio + o_rule), *done_ = (int *)(dio + o_one), *dtsrow = (int *)(dio + o_tsrow), *dflag = (int *)(dio + o_flag);
+    MOPT_HIP_TRY(ctx, hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream));
+    // ---- 1. previous step
+    if (do_prev) {
+        PTRY(mopt_launch_project_hess(ctx, n, 1, wk.H, wk.Bias, dx, wk.Q, wk.W6, wk.A));
+        PTRY(mopt_launch_matvec(ctx, n, 1, wk.A, dprevs, wk.u));
+        hipLaunchKernelGGL(k_prfo_prev, dim3(1), dim3(256), 0, ctx->stream, n, dpar, dst, dprevg, dprevs, wk.u, B_e, pre_move_norm);
+    }
+    // ---- 2. checked update: candidate in wk.A, accepted into wk.H on the device
+    if (do_upd) {
+        PTRY(mopt_launch_hess_update(ctx, n, 1, drule, done_, rule == MOPT_RULE_FLOWCHART, dx, dpx, dbg, dpg, wk.s, wk.y, wk.u, wk.Hy, wk.yd, wk.Av, wk.coef,
+                                     wk.info, wk.H, nullptr, wk.A, false, /*guard_sy=*/false));
+        PTRY(mopt_launch_norm_inf(ctx, n, 1, wk.A, wk.sigma));
+        hipLaunchKernelGGL(k_prfo_accept, dim3(1), dim3(1), 0, ctx->stream, (const UpdateCoef *)wk.coef, (const double *)wk.sigma, dflag);
+        int blocks = (int)(((size_t)n * n + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(k_copy_if, dim3(blocks), dim3(256), 0, ctx->stream, (size_t)n * n, (const int *)dflag, 1, (const double *)wk.A, wk.H);
+    }
+    // ---- 3. projected gradient and its norm; 4. eigh(H + bias); 5. scalar stage, step, tracked vector
+    PTRY(mopt_launch_project_grad(ctx, n, 1, dbg, dx, wk.gp, /*variant=*/1));
+    hipLaunchKernelGGL(k_norm1, dim3(1), dim3(256), 0, ctx->stream, n, wk.gp, dgn);
+    hipLaunchKernelGGL(k_set_gnorm, dim3(1), dim3(1), 0, ctx->stream, dst, dgn);
+    PTRY(mopt_launch_sym_add(ctx, n, 1, wk.H, wk.Bias, wk.A));
+    PTRY(mopt_eigh_auto(ctx, wk, n, 1, false));
+    PTRY(mopt_launch_vtg(ctx, n, 1, wk.Vt, wk.gp, wk.einfo, wk.gt_all));
+    if (have_ts) PTRY(mopt_launch_vtg(ctx, n, 1, wk.Vt, dts, wk.einfo, dov));
+    const size_t lds = (size_t)7 * n * 8 + (size_t)4 * n * 4 + 16;
+    if (!g_prfo_attr) {
+        MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_prfo_scalar, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+        g_prfo_attr = 1;
+    }
+    hipLaunchKernelGGL(k_prfo_scalar, dim3(1), dim3(64), lds, ctx->stream, n, (const mopt_rsprfo_params *)dpar, dst, wk.eigw, wk.perm, wk.einfo, wk.gt_all,
+                       (const double *)dov, have_ts, wk.coefout, dtsrow);
+    PTRY(mopt_launch_backtransform(ctx, n, 1, wk.Vt, wk.coefout, wk.einfo, wk.step));
+    PD2H(pin + p_out, wk.step, nv);
+    PD2H(pin + p_st, dst, sizeof(st));
+    PD2H(pin + p_row, dtsrow, sizeof(int));
+    PD2H(pin + p_bad, wk.einfo + 1, sizeof(int));
+    PD2H(pin + p_flag, dflag, sizeof(int));
+    if (ts_vec_out) {
+        hipLaunchKernelGGL(k_prfo_tsrow, dim3(1), dim3(256), 0, ctx->stream, n, wk.Vt, (const int *)dtsrow, wk.einfo, dov);
+        PD2H(pin + p_ts, dov, nv);
+    }
+    if (do_upd) PD2H(stage_H ? (void *)(pin + p_H) : (void *)H_out, wk.H, nn);      // (unchanged H when the update was not applied: same bits as the caller's)
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    int ts_row = -1, bad = 0, flag = 0;
+    std::memcpy(&flag, pin + p_flag, sizeof(int));
+    if (flag == 2) { *fallback = true; return MOPT_OK; }     // (H_out may have received the caller's own matrix back: harmless)
+    std::memcpy(step, pin + p_out, nv);
+    std::memcpy((void *)&st, pin + p_st, sizeof(st));
+    std::memcpy(&ts_row, pin + p_row, sizeof(int));
+    std::memcpy(&bad, pin + p_bad, sizeof(int));
+    const bool updated = flag == 1;
+    if (ts_vec_out && ts_row >= 0) std::memcpy(ts_vec_out, pin + p_ts, nv);
+    if (do_upd && stage_H && updated) std::memcpy(H_out, pin + p_H, nn);
+    if (!updated && H_out != hessian) std::memcpy(H_out, hessian, nn);
+    st.hess_updated = updated ? 1 : 0;
+    *state = st;
+    *timed_out = (bad & 8) != 0;
+    return MOPT_OK;
+}
+
 extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *params, mopt_rsprfo_state *state,
                                const double *hessian, const double *bias_hessian, const double *geom, const double *B_g,
                                const double *pre_geom, const double *pre_B_g, double B_e, const double *prev_gradient,
@@ -181,9 +302,26 @@ extern "C" int mopt_rsprfo_run(mopt_ctx *ctx, int n, const mopt_rsprfo_params *p
     const mopt_rsprfo_state st0 = *state;
     std::vector<double> hkeep;
     if (H_out == hessian && hessian && n > 0) hkeep.assign(hessian, hessian + (size_t)n * n);
-    bool timed_out = false;
+    bool timed_out = false, force_np = false;
+    static const bool no_fast = getenv("MOPT_PRFO_FAST") && atoi(getenv("MOPT_PRFO_FAST")) == 0;
+    if (!no_fast && ctx && params && geom && B_g && step && H_out && hessian && n >= 3 && n % 3 == 0 && n <= MOPT_MAX_N && !mopt_debug_poison_on() &&
+        params->rule >= 0 && params->rule < MOPT_RULE_COUNT) {
+        bool fallback = false;
+        const int rcf = rsprfo_run_fast(ctx, n, params, state, hessian, bias_hessian, geom, B_g, pre_geom, pre_B_g, B_e, prev_gradient, prev_move_vector,
+                                        pre_move_norm, ts_vec, step, H_out, ts_vec_out, &timed_out, &fallback);
+        if (rcf != MOPT_OK) return rcf;
+        if (!fallback && !timed_out) return MOPT_OK;
+        // (spectrum check needed, or a hand-off time-out: start over from the caller's inputs on the path that handles them)
+        *state = st0;
+        if (!hkeep.empty() && H_out == hessian) std::memcpy(H_out, hkeep.data(), hkeep.size() * sizeof(double));
+        force_np = timed_out;
+        timed_out = false;
+    }
+    const bool saved_np = ctx->tri_no_persist;
+    if (force_np) ctx->tri_no_persist = true;
     int rc = rsprfo_run_once(ctx, n, params, state, hessian, bias_hessian, geom, B_g, pre_geom, pre_B_g, B_e, prev_gradient, prev_move_vector,
                              pre_move_norm, ts_vec, step, H_out, ts_vec_out, &timed_out);
+    ctx->tri_no_persist = saved_np;
     if (rc == MOPT_OK && timed_out) {
         *state = st0;
         const bool saved = ctx->tri_no_persist;

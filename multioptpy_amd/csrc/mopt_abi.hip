@@ -648,6 +648,9 @@ extern "C" int mopt_mf_rsirfo_finish(mopt_ctx *ctx, int n, const mopt_rsirfo_par
 }
 
 // (for k_prfo.hip: the cached workspace of a single small geometry)
+int mopt_ws_get(mopt_ctx *ctx, int n, bool bias, size_t io_bytes, RsirfoWork **wk_out, void **io_out) {
+    return ws_get(ctx, n, 1, true, bias, false, io_bytes, wk_out, io_out);
+}
 int mopt_ws_get_small(mopt_ctx *ctx, int n, RsirfoWork **wk_out) {
     void *io = nullptr;
     return ws_get(ctx, n, 1, true, false, false, 256, wk_out, &io);

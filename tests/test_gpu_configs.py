@@ -952,3 +952,38 @@ def test_small_prfo_kernel_vs_oracle(natoms, method, order):
     print(f"N = {natoms} {method} order {order}: {compared} steps compared, worst deviation {worst:.2e}")
     # (saddle order 2 near a minimum: both lowest modes are shifted to min_negative_eigval -- a degenerate pair from the second step on)
     assert compared >= (2 if order == 1 else 1)
+
+
+def test_rsprfo_update_rejected_by_spectrum_check():
+    """A Hessian with one stiff mode (3e6): every candidate of the quasi-Newton update has an eigenvalue above 1e6 and the reference rejects
+    it after looking at the spectrum (rsprfo.py:1236-1250).  Neither the one-workgroup kernel nor the fast general path takes that decision on
+    its own (the infinity-norm bound fails): both hand the call to the path that computes the spectrum; the Hessian must come back unchanged and the steps must be those of
+    that path (MOPT_SMALL=0 MOPT_PRFO_FAST=0) up to the conditioning.  (No comparison of the steps with the
+    oracle here: at a condition number of 3e10 the soft eigenvalues carry absolute errors of eps * 3e6 in LAPACK and on the device alike,
+    next to a shift threshold of 1e-6.)"""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests', 'golden')); "
+            "import numpy as np, cases; from multioptpy_amd.Optimizer.rsprfo import EnhancedRSPRFO\n"
+            "out = []\n"
+            "for N in (7, 30):\n"
+            "    n = 3 * N; x = cases.cluster(N, jitter=0.05) * 0.99\n"
+            "    v = np.random.default_rng(N).normal(size=n); v /= np.linalg.norm(v)\n"
+            "    H0 = cases.lj(x, hessian=True)[2] + 3.0e6 * np.outer(v, v)\n"
+            "    o = EnhancedRSPRFO(method='rsprfo_bofill', saddle_order=1, element_list=['Ar'] * N); o.set_hessian(H0.copy()); o.set_bias_hessian(np.zeros((n, n)))\n"
+            "    px = pg = []; pe = 0.0\n"
+            "    for it in range(3):\n"
+            "        e, g = cases.lj(x)[:2]; mv = o.run(x.reshape(-1, 1), g.reshape(-1, 1), pg, px, e, pe, [], [], g.reshape(-1, 1), pg)\n"
+            "        assert o.last_info['hess_updated'] == 0 and np.array_equal(np.asarray(o.hessian), H0)\n"
+            "        px, pg, pe = x.reshape(-1, 1).copy(), g.reshape(-1, 1).copy(), e; st = np.asarray(mv).reshape(N, 3); x = x - st * min(1.0, 0.1 / max(np.linalg.norm(st), 1e-12)); out.append(np.asarray(mv).ravel())\n"
+            "np.save(sys.argv[1], np.concatenate(out))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"MOPT_SMALL": "0", "MOPT_PRFO_FAST": "0"}):
+        f = os.path.join("/tmp", f"mopt_rej_{len(outs)}_{os.getpid()}.npy")
+        r = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(f))
+        os.remove(f)
+    # (steps without a pending update -- the first of each run -- stay on the fast paths: equal up to the conditioning, not bit for bit)
+    assert np.abs(outs[0] - outs[1]).max() < 1e-3 * np.abs(outs[1]).max()
