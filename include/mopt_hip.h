@@ -357,6 +357,14 @@ int mopt_afir(mopt_ctx *ctx, int N, const double *X, const double *cov, int n1, 
  * anharmonic, D = 0 contributes nothing).  Out: E (1), grad (N x 3), H (3N x 3N). */
 int mopt_keep_pot(mopt_ctx *ctx, int N, const double *X, int npairs, const int *pairs, const double *kr, double *E, double *grad, double *H);
 
+/* Angle (kind 0) and dihedral-angle (kind 1) restraints E = sum_t 1/2 k_t (angle_t - angle0_t)^2 with the reference's treatment of the singular
+ * geometries: StructKeepAnglePotential.calc_energy (Potential/keep_angle_potential.py:58-224: Taylor branches within 1e-3 rad of 0 / 180 degrees)
+ * and StructKeepDihedralAnglePotential.calc_energy (Potential/keep_dihedral_angle_potential.py:60-154: periodic difference, smoothstep switch-off
+ * near collinear bonds).  Gradient and Hessian are exact derivatives of those expressions (hyper-dual evaluation on the device) -- what the
+ * reference gets from torch.func.jacrev / hessian on the CPU, Potential/potential.py:127-152.  X: N x 3 (bohr); atoms: nterms x 3 (4) 0-based;
+ * kp: nterms x 2 = (spring constant hartree / rad^2, equilibrium angle in radians).  Out: E (1), grad (N x 3), H (3N x 3N). */
+int mopt_keep_angle(mopt_ctx *ctx, int kind, int N, const double *X, int nterms, const int *atoms, const double *kp, double *E, double *grad, double *H);
+
 /* ---- model Hessians ----------------------------------------------------------------
  * ApproxHessian.main (multioptpy/ModelHessian/approx_hessian.py:30-112) dispatches by name; on the device:
  *   MOPT_MODEL_FISCHERD3OLD  FischerD3ApproxHessianOld.main (ModelHessian/fischerd3old.py:355-381), the `-modelhess` default

@@ -81,6 +81,8 @@ def _proto(lib):
                                          DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
         lib.mopt_crsirfo_run_rowspace.argtypes = [vp, C.c_int, C.c_int, C.POINTER(_abi.RsirfoParams), C.POINTER(_abi.RsirfoState),
                                          DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP, DP]
+    if hasattr(lib, "mopt_keep_angle"):
+        lib.mopt_keep_angle.argtypes = [vp, C.c_int, C.c_int, DP, C.c_int, IP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_keep_pot"):
         lib.mopt_keep_pot.argtypes = [vp, C.c_int, DP, C.c_int, IP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_afir"):

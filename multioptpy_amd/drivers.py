@@ -59,7 +59,7 @@ class ConvergenceChecker:
 
 def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, saddle_order=0, NSTEP=300, FC_COUNT=-1,
                   max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False, model_hessian=None,
-                  MFC_COUNT=50, afir=None, keep_pot=None, projection_constraint=None):
+                  MFC_COUNT=50, afir=None, keep_pot=None, projection_constraint=None, keep_angle=None, keep_dihedral=None):
     """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy).
     projection_constraint: `-pc` as dict(conditions=[...], atoms=[[...], ...], constants=[...]) (interface.py:453-475): a ProjectOutConstrain
     object goes to CalculateMoveVector, whose crsirfo_* keys then build the constrained optimizer (optimizer.py:450-451, optimization.py:1810-1829).
@@ -124,6 +124,13 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
             from .Potential.keep_potential import keep_pot_sum
             ke, kg, kh = keep_pot_sum(geometry, [p["pair"] for p in keep_pot], [p["k"] for p in keep_pot], [p["r0"] for p in keep_pot])
             bias_energy, bias_gradient, bias_hessian = bias_energy + ke, bias_gradient + kg, bias_hessian + kh
+        for terms, dih in ((keep_angle, False), (keep_dihedral, True)):
+            if terms:
+                # angle / dihedral-angle restraints (`-ka k theta i,j,k`, `-kda k phi i,j,k,l`; Potential/keep_angle_potential.py,
+                # keep_dihedral_angle_potential.py): list of dict(atoms=[...] 1-based, k=..., angle=... degrees)
+                from .Potential.keep_angle_potential import keep_angle_sum
+                ke, kg, kh = keep_angle_sum(geometry, [p["atoms"] for p in terms], [p["k"] for p in terms], [p["angle"] for p in terms], dihedral=dih)
+                bias_energy, bias_gradient, bias_hessian = bias_energy + ke, bias_gradient + kg, bias_hessian + kh
         if it == 0:                                                     # _save_init_geometry (optimization.py:2206-2217)
             centre = tools.calc_center(geometry, element_list)
             pre_geometry = (geometry - centre) - centre
@@ -181,7 +188,7 @@ def make_band(frames_ang, partition):
 
 def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
                   ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999, devices=None,
-                  transport="rccl", model_hessian=None, MFC_COUNT=50, align_distances=0, climbing_image=(999999, 999999), afir=None, keep_pot=None):
+                  transport="rccl", model_hessian=None, MFC_COUNT=50, align_distances=0, climbing_image=(999999, 999999), afir=None, keep_pot=None, keep_angle=None, keep_dihedral=None):
     """Band relaxation as in nebmain: with FC_COUNT != -1 the Hessian-based branch (`-fc`: RFOOptimizer on a BNEB force),
     otherwise the default FIRE optimizer, replaced by steepest descent from iteration `steepest_descent` on (`-sd`,
     neb.py:794-804, 939-948).
@@ -231,7 +238,7 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
         if hessians is not None and rfo_branch:
             optimizer.set_image_hessians(hessians)
         E_raw = E.copy()
-        if afir is not None or keep_pot:
+        if afir is not None or keep_pot or keep_angle or keep_dihedral:
             Bh = []
             for i in range(len(X)):
                 be, bg, bh = 0.0, np.zeros_like(X[i]), np.zeros((3 * X.shape[1], 3 * X.shape[1]))
@@ -244,6 +251,11 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
                     from .Potential.keep_potential import keep_pot_sum
                     e1, g1, h1 = keep_pot_sum(X[i], [p["pair"] for p in keep_pot], [p["k"] for p in keep_pot], [p["r0"] for p in keep_pot])
                     be, bg, bh = be + e1, bg + g1, bh + h1
+                for terms, dih in ((keep_angle, False), (keep_dihedral, True)):
+                    if terms:
+                        from .Potential.keep_angle_potential import keep_angle_sum
+                        e1, g1, h1 = keep_angle_sum(X[i], [p["atoms"] for p in terms], [p["k"] for p in terms], [p["angle"] for p in terms], dihedral=dih)
+                        be, bg, bh = be + e1, bg + g1, bh + h1
                 E[i] += be
                 G[i] += bg
                 Bh.append(bh)

@@ -1079,9 +1079,66 @@ def g10d_ts_modifier():
     print("G10d:", len(out["tags"]), "geometries")
 
 
+def g14b_keep_angle():
+    """G14b: StructKeepAnglePotential / StructKeepDihedralAnglePotential (Potential/keep_angle_potential.py, keep_dihedral_angle_potential.py):
+    energy, torch.func.jacrev gradient and torch.func.hessian Hessian as Potential/potential.py:127-152 forms them -- ordinary geometries, angles
+    within 1e-3 rad of 0 and 180 degrees (Taylor branches), equilibrium angles 0 / 180 / general, dihedrals across the +-180 wrap and inside the
+    collinearity switch."""
+    import torch
+    from multioptpy.Potential.keep_angle_potential import StructKeepAnglePotential
+    from multioptpy.Potential.keep_dihedral_angle_potential import StructKeepDihedralAnglePotential
+    rng = np.random.default_rng(1414)
+    N = 6
+    cases_ = []
+    base = rng.normal(0.0, 1.5, (N, 3))
+
+    def with_angle(theta):          # atoms 1-2-3 with the given angle at atom 2
+        x = base.copy()
+        x[1] = [0.0, 0.0, 0.0]
+        x[0] = [1.7, 0.0, 0.0]
+        x[2] = [1.3 * math.cos(theta), 1.3 * math.sin(theta), 0.0]
+        return x
+    import math
+    for theta, th0 in ((1.9, 109.5), (0.7, 60.0), (math.pi - 4e-4, 180.0), (math.pi - 4e-4, 120.0), (3e-4, 0.0), (3e-4, 90.0), (2.5, 180.0), (0.4, 0.0), (math.pi - 0.2, 170.0)):
+        cases_.append(("angle", with_angle(theta) + rng.normal(0, 1e-5, (N, 3)) * (0 if theta < 1e-3 or theta > math.pi - 1e-3 else 1), [1, 2, 3], 0.35, th0))
+    cases_.append(("angle", base.copy(), [4, 6, 5], 0.2, 100.0))
+
+    def with_dihedral(phi, bend=1.9):      # atoms 1-2-3-4
+        x = base.copy()
+        x[1] = [0.0, 0.0, 0.0]
+        x[2] = [1.5, 0.0, 0.0]
+        x[0] = [1.2 * math.cos(bend), 1.2 * math.sin(bend), 0.0]
+        x[3] = [1.5 - 1.1 * math.cos(bend), 1.1 * math.sin(bend) * math.cos(phi), 1.1 * math.sin(bend) * math.sin(phi)]
+        return x
+    for phi, ph0, bend in ((1.0, 60.0, 1.9), (-2.9, 175.0, 1.9), (3.0, -170.0, 2.0), (0.3, 0.0, 1.2), (2.0, 120.0, math.pi - 6e-5), (1.2, 30.0, math.pi - 2e-5), (-1.0, -90.0, 1.7)):
+        cases_.append(("dihedral", with_dihedral(phi, bend), [1, 2, 3, 4], 0.25, ph0))
+    cases_.append(("dihedral", base.copy(), [2, 5, 3, 6], 0.15, 45.0))
+    out = {"ncase": np.array(len(cases_))}
+    for ci, (kind, x, atoms, k, ang) in enumerate(cases_):
+        tag = f"a{ci:02d}"
+        if kind == "angle":
+            pot = StructKeepAnglePotential(keep_angle_spring_const=k, keep_angle_angle=ang, keep_angle_atom_pairs=atoms)
+        else:
+            pot = StructKeepDihedralAnglePotential(keep_dihedral_angle_spring_const=k, keep_dihedral_angle_angle=ang, keep_dihedral_angle_atom_pairs=atoms)
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        E = pot.calc_energy(xt, [])
+        g = torch.func.jacrev(pot.calc_energy, argnums=0)(xt, [])
+        H = torch.func.hessian(pot.calc_energy, argnums=0)(xt, [])
+        out[tag + "_kind"] = np.array(kind)
+        out[tag + "_x"] = x
+        out[tag + "_atoms"] = np.array(atoms)
+        out[tag + "_k"] = np.array(k)
+        out[tag + "_angle_deg"] = np.array(ang)
+        out[tag + "_E"] = np.array(float(E))
+        out[tag + "_g"] = g.detach().numpy().copy()
+        out[tag + "_H"] = H.detach().numpy().reshape(3 * N, 3 * N).copy()
+    np.savez_compressed(os.path.join(HERE, "g14b_keep_angle.npz"), **out)
+    print("G14b:", len(cases_), "cases")
+
+
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g10d", "g11", "g12", "g12b", "g13", "g14", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g10d", "g11", "g12", "g12b", "g13", "g14", "g14b", "g15"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -1100,6 +1157,8 @@ if __name__ == "__main__":
         g10c_lindh2007d3()
     if "g15" in which:
         g15_mf_rsirfo()
+    if "g14b" in which:
+        g14b_keep_angle()
     if "g10d" in which:
         g10d_ts_modifier()
     if "g12b" in which:

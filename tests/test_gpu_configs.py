@@ -592,6 +592,30 @@ def test_keep_pot_bias_vs_reference():
     assert np.abs(g - sum(r[1] for r in ref)).max() < 1e-13 and np.abs(H - sum(r[2] for r in ref)).max() < 1e-12
 
 
+def test_keep_angle_and_dihedral_bias_vs_reference():
+    """G14b: angle and dihedral-angle restraints on the device (hyper-dual evaluation of the reference's expressions: Taylor branches near
+    0 / 180 degrees, periodic wrap, collinearity switch, the single-precision equilibrium angle) against the reference's torch autograd outputs;
+    two terms in one call add up."""
+    import test_oracle_golden as tog
+    from multioptpy_amd.Potential.keep_angle_potential import StructKeepAnglePotential, StructKeepDihedralAnglePotential, keep_angle_sum
+
+    def fn(kind, x, atoms, k, ang):
+        if kind == "angle":
+            pot = StructKeepAnglePotential(keep_angle_spring_const=k, keep_angle_angle=ang, keep_angle_atom_pairs=atoms)
+        else:
+            pot = StructKeepDihedralAnglePotential(keep_dihedral_angle_spring_const=k, keep_dihedral_angle_angle=ang, keep_dihedral_angle_atom_pairs=atoms)
+        return pot.calc_energy_gradient_hessian(x)
+    print("angle restraints on the device vs reference: worst relative Hessian deviation", tog._check_g14b(fn, 1e-9))
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g14b_keep_angle.npz"))
+    x = z["a09_x"]
+    E2, g2, H2 = keep_angle_sum(x, [[4, 6, 5], [1, 2, 3]], [0.2, 0.35], [100.0, 109.5])
+    Ea, ga, Ha = keep_angle_sum(x, [[4, 6, 5]], [0.2], [100.0])
+    Eb, gb, Hb = keep_angle_sum(x, [[1, 2, 3]], [0.35], [109.5])
+    assert abs(E2 - Ea - Eb) < 1e-15 and np.abs(g2 - ga - gb).max() < 1e-15 and np.abs(H2 - Ha - Hb).max() < 1e-14
+    with pytest.raises(Exception):
+        keep_angle_sum(x, [[1, 1, 2]], [0.1], [90.0])
+
+
 def test_afir_bias_vs_reference():
     """G11: AFIR bias energy / gradient / Hessian on the device against the reference's torch-autograd values (<= 1e-8; ~1e-16)."""
     import os

@@ -571,13 +571,13 @@ def test_optmain_driver_vs_reference(tag):
     print("optmain", tag, "worst move-vector deviation from the reference", worst)
 
 
-@pytest.mark.parametrize("kind", ["keep", "afir", "both"])
+@pytest.mark.parametrize("kind", ["keep", "afir", "both", "angles"])
 def test_optmain_driver_with_bias_vs_oracle(kind):
     """a23 + f3: the in-memory optmain iteration with bias potentials -- harmonic distance restraints (mopt_keep_pot) and / or the AFIR
     term (mopt_afir): bias energy and gradient added to the calculator's, bias Hessian handed to the optimizer -- against the oracle's
     driver with the oracle's analytic bias (both pinned by the reference's autograd outputs, G11 / G14): six iterations on Ar7."""
     import cases
-    from oracle import driver, projection as pj, afir as oafir, keep_pot as okp, model_hessian as mh
+    from oracle import driver, projection as pj, afir as oafir, keep_pot as okp, keep_angle as oka, model_hessian as mh
     from multioptpy_amd import drivers
     N = 7
     x0 = cases.cluster(N, jitter=0.2) * cases.BOHR2ANG
@@ -585,6 +585,8 @@ def test_optmain_driver_with_bias_vs_oracle(kind):
     cov = mh.element_params(el)["cov"]
     kp = [dict(pair=[1, 4], k=0.05, r0=3.2), dict(pair=[4, 6], k=0.1, r0=4.5)] if kind in ("keep", "both") else None
     af = dict(gamma=40.0, fragm_1=[1, 2, 3], fragm_2=[5, 6, 7]) if kind in ("afir", "both") else None
+    ka = [dict(atoms=[1, 2, 3], k=0.08, angle=75.0), dict(atoms=[4, 5, 6], k=0.05, angle=110.0)] if kind == "angles" else None
+    kd = [dict(atoms=[1, 2, 5, 7], k=0.06, angle=40.0)] if kind == "angles" else None
 
     def bias(x):
         E, g, H = 0.0, np.zeros((N, 3)), np.zeros((3 * N, 3 * N))
@@ -594,10 +596,14 @@ def test_optmain_driver_with_bias_vs_oracle(kind):
         for p in kp or []:
             e1, g1, h1 = okp.keep_pot(x, p["pair"], p["k"], p["r0"])
             E, g, H = E + e1, g + g1, H + h1
+        for terms, dih in ((ka, False), (kd, True)):
+            for p in terms or []:
+                e1, g1, h1 = oka.energy_gradient_hessian(x, [a - 1 for a in p["atoms"]], p["k"], oka.deg2rad_as_reference(p["angle"]), dihedral=dih)
+                E, g, H = E + e1, g + g1, H + h1
         return E, g, H
 
     ra, rb = [], []
-    drivers.optmain_steps(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=ra, afir=af, keep_pot=kp)
+    drivers.optmain_steps(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=ra, afir=af, keep_pot=kp, keep_angle=ka, keep_dihedral=kd)
     driver.run_optmain(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=rb, bias=bias)
     assert len(ra) == len(rb) >= 3
     worst = 0.0

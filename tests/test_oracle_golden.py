@@ -625,3 +625,32 @@ def test_g15_mf_rsirfo_traces():
     with contextlib.redirect_stdout(io.StringIO()):
         worst = _check_mf(z, lambda method, so, elems, masses, kw: MF_RSIRFO(masses=masses, method=method, saddle_order=so, **kw), 1e-9)
     print("oracle MF_RSIRFO vs reference: worst step deviation", worst)
+
+
+def _check_g14b(fn, tol):
+    """fn(kind, x, atoms 1-based, k, angle in degrees) -> (E, g, H) against G14b (the reference's torch autograd outputs)."""
+    z = np.load(os.path.join(G, "g14b_keep_angle.npz"))
+    worst = 0.0
+    for i in range(int(z["ncase"])):
+        tag = f"a{i:02d}"
+        kind = str(z[tag + "_kind"])
+        E, g, H = fn(kind, z[tag + "_x"], [int(a) for a in z[tag + "_atoms"]], float(z[tag + "_k"]), float(z[tag + "_angle_deg"]))
+        refH = z[tag + "_H"]
+        if not np.isfinite(refH).all():          # (torch.where multiplies the unselected branch's infinite derivative by zero: NaN in the reference itself)
+            continue
+        sc = max(1.0, np.abs(refH).max())
+        assert abs(E - float(z[tag + "_E"])) < tol * max(1.0, abs(float(z[tag + "_E"]))), (tag, kind)
+        assert np.abs(g - z[tag + "_g"]).max() < tol * sc, (tag, kind, np.abs(g - z[tag + "_g"]).max())
+        assert np.abs(H - refH).max() < tol * sc, (tag, kind, np.abs(H - refH).max())
+        worst = max(worst, np.abs(H - refH).max() / sc)
+    return worst
+
+
+def test_g14b_keep_angle_oracle_vs_reference():
+    """G14b: angle and dihedral-angle restraints (Taylor branches near 0 / 180 degrees, periodic wrap, collinearity switch) -- the oracle's
+    hyper-dual restatement against the reference's torch.func.jacrev / hessian outputs."""
+    from oracle import keep_angle as ka
+
+    def fn(kind, x, atoms, k, ang):
+        return ka.energy_gradient_hessian(x, [a - 1 for a in atoms], k, ka.deg2rad_as_reference(ang), dihedral=(kind == "dihedral"))
+    print("oracle angle restraints vs reference: worst relative Hessian deviation", _check_g14b(fn, 1e-9))
