@@ -363,7 +363,13 @@ int mopt_keep_pot(mopt_ctx *ctx, int N, const double *X, int npairs, const int *
  * near collinear bonds).  Gradient and Hessian are exact derivatives of those expressions (hyper-dual evaluation on the device) -- what the
  * reference gets from torch.func.jacrev / hessian on the CPU, Potential/potential.py:127-152.  X: N x 3 (bohr); atoms: nterms x 3 (4) 0-based;
  * kp: nterms x 2 = (spring constant hartree / rad^2, equilibrium angle in radians).  Out: E (1), grad (N x 3), H (3N x 3N). */
+/* kind 2: out-of-plane-angle restraints, StructKeepOutofPlainAnglePotential.calc_energy (Potential/keep_outofplain_angle_potential.py:33-146): atoms per
+ * term = centre, probe, two plane atoms; zero inside the collinearity guard. */
 int mopt_keep_angle(mopt_ctx *ctx, int kind, int N, const double *X, int nterms, const int *atoms, const double *kp, double *E, double *grad, double *H);
+/* Fragment-centre distance restraint 1/2 k (|c1 - c2| - r0)^2, StructKeepPotentialv2.calc_energy (Potential/keep_potential.py:79-115): frag1 / frag2
+ * 0-based atom lists (n1 + n2 <= 64), k in hartree / bohr^2, r0 in bohr. */
+int mopt_keep_pot_v2(mopt_ctx *ctx, int N, const double *X, int n1, const int *frag1, int n2, const int *frag2, double k, double r0, double *E, double *grad,
+                     double *H);
 
 /* ---- model Hessians ----------------------------------------------------------------
  * ApproxHessian.main (multioptpy/ModelHessian/approx_hessian.py:30-112) dispatches by name; on the device:

@@ -8,6 +8,8 @@
 // off the result -- exact derivatives of exactly the expression the reference differentiates, branch by branch, with no formula for the
 // second derivatives of an angle written out by hand.  45 (78) threads per term; the terms of a call are added one after the other
 // (deterministic sum; they may share atoms).
+#include <vector>
+
 #include "pipeline.h"
 
 namespace mopt {
@@ -94,6 +96,49 @@ __device__ HD dihedral_energy(const HD3 *p, double k, double phi0) {
     return ((0.5 * k) * diff * diff) * s1 * s2;
 }
 
+// keep_outofplain_angle_potential.py:33-146; p: centre, probe, plane atom 1, plane atom 2; theta0 in radians
+__device__ HD outofplane_energy(const HD3 *p, double k, double theta0) {
+    const HD3 a1 = p[1] - p[0], a2 = p[2] - p[0], a3 = p[3] - p[0];
+    const HD3 nv = cross(a2, a3);
+    const HD nsq = dot(nv, nv);
+    if (nsq.v < 1e-8) return hd_const(0.0);                  // undefined plane (collinear base vectors): energy and derivatives forced to zero
+    const HD3 nh = scale(nv, hd_const(1.0) / hd_clamp_min(hd_sqrt(nsq), 1e-12));
+    const HD h = dot(a1, nh);
+    const HD a1n = hd_sqrt(dot(a1, a1));
+    const HD rproj = hd_sqrt(hd_clamp_min(a1n * a1n - h * h, 0.0));
+    const HD diff = hd_atan2(h, rproj) - theta0;
+    return (0.5 * k) * diff * diff;
+}
+
+// StructKeepPotentialv2.calc_energy (keep_potential.py:79-115): 1/2 k (|c1 - c2| - r0)^2 between the centroids of two atom lists.  One workgroup;
+// variables = the coordinates of the n1 + n2 list entries (an atom may occur more than once: its contributions add up, hence the atomics).
+__global__ void __launch_bounds__(256) k_bias_fragment_distance(int N, const double *__restrict__ x, int n1, int n2, const int *__restrict__ atoms, double k,
+                                                                double r0, double *__restrict__ E, double *__restrict__ g, double *__restrict__ H) {
+    const int nv = 3 * (n1 + n2), np_ = nv * (nv + 1) / 2, n = 3 * N;
+    for (int t = threadIdx.x; t < np_; t += blockDim.x) {
+        int pi = 0, r = t;
+        while (r >= nv - pi) { r -= nv - pi; ++pi; }
+        const int pj = pi + r;
+        HD3 c[2] = {{hd_const(0.0), hd_const(0.0), hd_const(0.0)}, {hd_const(0.0), hd_const(0.0), hd_const(0.0)}};
+        for (int a = 0; a < n1 + n2; ++a) {
+            const int at = atoms[a], f = a < n1 ? 0 : 1;
+            HD q[3];
+            for (int d = 0; d < 3; ++d) { const int var = 3 * a + d; q[d] = {x[3 * at + d], var == pi ? 1.0 : 0.0, var == pj ? 1.0 : 0.0, 0.0}; }
+            c[f] = {c[f].x + q[0], c[f].y + q[1], c[f].z + q[2]};
+        }
+        const HD3 c1 = scale(c[0], hd_const(1.0 / n1)), c2 = scale(c[1], hd_const(1.0 / n2));
+        const HD3 v = c1 - c2;
+        const HD dist = hd_clamp_min(hd_sqrt(dot(v, v)), 1e-12);
+        const HD dd = dist - r0;
+        const HD e = (0.5 * k) * dd * dd;
+        const int row = 3 * atoms[pi / 3] + pi % 3, col = 3 * atoms[pj / 3] + pj % 3;
+        if (t == 0) E[0] = e.v;
+        if (pi == pj) atomicAdd(&g[row], e.a);
+        atomicAdd(&H[(size_t)row * n + col], e.c);
+        if (pi != pj) atomicAdd(&H[(size_t)col * n + row], e.c);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bias_zero(size_t total, double *__restrict__ H, int n, double *__restrict__ g, double *__restrict__ E) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) H[i] = 0.0;
@@ -101,8 +146,8 @@ __global__ void __launch_bounds__(256) k_bias_zero(size_t total, double *__restr
     if (i == 0) E[0] = 0.0;
 }
 
-// one workgroup of 128 threads; NA atoms per term (3: angle, 4: dihedral); atoms: [nterms][NA] 0-based; kp: [nterms][2] = (k, angle in radians)
-template <int NA>
+// one workgroup of 128 threads; NA atoms per term (3: angle, 4: dihedral or out-of-plane); atoms: [nterms][NA] 0-based; kp: [nterms][2] = (k, angle in radians)
+template <int NA, int KIND>
 __global__ void __launch_bounds__(128) k_bias_angle_terms(int N, const double *__restrict__ x, int nterms, const int *__restrict__ atoms,
                                                           const double *__restrict__ kp, double *__restrict__ E, double *__restrict__ g, double *__restrict__ H) {
     constexpr int NV = 3 * NA, NP = NV * (NV + 1) / 2;
@@ -125,7 +170,7 @@ __global__ void __launch_bounds__(128) k_bias_angle_terms(int N, const double *_
                 p[a] = {c[0], c[1], c[2]};
             }
             const double k = kp[2 * term], ang = kp[2 * term + 1];
-            const HD e = (NA == 3) ? angle_energy(p, k, ang) : dihedral_energy(p, k, ang);
+            const HD e = (KIND == 0) ? angle_energy(p, k, ang) : (KIND == 1) ? dihedral_energy(p, k, ang) : outofplane_energy(p, k, ang);
             const int row = 3 * atoms[NA * term + pi / 3] + pi % 3, col = 3 * atoms[NA * term + pj / 3] + pj % 3;
             if (t == 0) E[0] += e.v;
             if (pi == pj) g[row] += e.a;
@@ -138,7 +183,8 @@ __global__ void __launch_bounds__(128) k_bias_angle_terms(int N, const double *_
 
 }  // namespace mopt
 
-// kind 0: angle restraints (3 atoms per term), kind 1: dihedral-angle restraints (4 atoms per term).  X: N x 3 (bohr); atoms: nterms x (3 | 4)
+// kind 0: angle restraints (3 atoms per term), kind 1: dihedral-angle restraints, kind 2: out-of-plane-angle restraints (4 atoms per term: centre,
+// probe, two plane atoms).  X: N x 3 (bohr); atoms: nterms x (3 | 4)
 // 0-based, all different within a term; kp: nterms x 2 = (spring constant in hartree / rad^2, equilibrium angle in RADIANS).
 // Out: E (1), grad (N x 3), H (3N x 3N).  Host pointers.
 extern "C" int mopt_keep_angle(mopt_ctx *ctx, int kind, int N, const double *X, int nterms, const int *atoms, const double *kp, double *E, double *grad,
@@ -146,7 +192,7 @@ extern "C" int mopt_keep_angle(mopt_ctx *ctx, int kind, int N, const double *X, 
     using namespace mopt;
     if (!ctx) return MOPT_E_ARG;
     const int na = kind == 0 ? 3 : 4;
-    if ((kind != 0 && kind != 1) || N < 1 || 3 * N > MOPT_MAX_N || nterms < 0 || !X || (nterms > 0 && (!atoms || !kp)) || !E || !grad || !H) {
+    if (kind < 0 || kind > 2 || N < 1 || 3 * N > MOPT_MAX_N || nterms < 0 || !X || (nterms > 0 && (!atoms || !kp)) || !E || !grad || !H) {
         ctx->err = "mopt_keep_angle: bad argument";
         return MOPT_E_ARG;
     }
@@ -175,12 +221,50 @@ extern "C" int mopt_keep_angle(mopt_ctx *ctx, int kind, int N, const double *X, 
         hipLaunchKernelGGL(k_bias_zero, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, nn, (double *)d, n, (double *)(d + o_g), (double *)(d + o_E));
         if (nterms > 0) {
             if (kind == 0)
-                hipLaunchKernelGGL(k_bias_angle_terms<3>, dim3(1), dim3(128), 0, ctx->stream, N, (const double *)(d + o_x), nterms, (const int *)(d + o_a),
+                hipLaunchKernelGGL((k_bias_angle_terms<3, 0>), dim3(1), dim3(128), 0, ctx->stream, N, (const double *)(d + o_x), nterms, (const int *)(d + o_a),
+                                   (const double *)(d + o_k), (double *)(d + o_E), (double *)(d + o_g), (double *)d);
+            else if (kind == 1)
+                hipLaunchKernelGGL((k_bias_angle_terms<4, 1>), dim3(1), dim3(128), 0, ctx->stream, N, (const double *)(d + o_x), nterms, (const int *)(d + o_a),
                                    (const double *)(d + o_k), (double *)(d + o_E), (double *)(d + o_g), (double *)d);
             else
-                hipLaunchKernelGGL(k_bias_angle_terms<4>, dim3(1), dim3(128), 0, ctx->stream, N, (const double *)(d + o_x), nterms, (const int *)(d + o_a),
+                hipLaunchKernelGGL((k_bias_angle_terms<4, 2>), dim3(1), dim3(128), 0, ctx->stream, N, (const double *)(d + o_x), nterms, (const int *)(d + o_a),
                                    (const double *)(d + o_k), (double *)(d + o_E), (double *)(d + o_g), (double *)d);
         }
+    }
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(E, d + o_E, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(grad, d + o_g, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(H, d, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+// StructKeepPotentialv2 (fragment-centre distance restraint): frag1 / frag2 0-based atom lists (n1 + n2 <= 64; repeats allowed), k in
+// hartree / bohr^2, r0 in bohr.  Out: E (1), grad (N x 3), H (3N x 3N).  Host pointers.
+extern "C" int mopt_keep_pot_v2(mopt_ctx *ctx, int N, const double *X, int n1, const int *frag1, int n2, const int *frag2, double k, double r0, double *E,
+                                double *grad, double *H) {
+    using namespace mopt;
+    if (!ctx) return MOPT_E_ARG;
+    if (N < 1 || 3 * N > MOPT_MAX_N || n1 < 1 || n2 < 1 || n1 + n2 > 64 || !X || !frag1 || !frag2 || !E || !grad || !H) { ctx->err = "mopt_keep_pot_v2: bad argument"; return MOPT_E_ARG; }
+    std::vector<int> at;
+    for (int a = 0; a < n1; ++a) at.push_back(frag1[a]);
+    for (int a = 0; a < n2; ++a) at.push_back(frag2[a]);
+    for (int v : at) if (v < 0 || v >= N) { ctx->err = "mopt_keep_pot_v2: atom index out of range (0-based)"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    const int n = 3 * N;
+    const size_t nn = (size_t)n * n;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_g = al(nn * 8), o_E = o_g + al((size_t)n * 8), o_x = o_E + 256, o_a = o_x + al((size_t)n * 8);
+    char *d = nullptr;
+    MOPT_HIP_TRY(ctx, hipMalloc((void **)&d, o_a + 512));
+    struct Free { char *p; ~Free() { if (p) hipFree(p); } } guard{d};
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(d + o_x, X, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(d + o_a, at.data(), at.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    {
+        mopt_scope sc(ctx, "bias_keep", 2);
+        hipLaunchKernelGGL(k_bias_zero, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, nn, (double *)d, n, (double *)(d + o_g), (double *)(d + o_E));
+        hipLaunchKernelGGL(k_bias_fragment_distance, dim3(1), dim3(256), 0, ctx->stream, N, (const double *)(d + o_x), n1, n2, (const int *)(d + o_a), k, r0,
+                           (double *)(d + o_E), (double *)(d + o_g), (double *)d);
     }
     MOPT_HIP_TRY(ctx, hipGetLastError());
     MOPT_HIP_TRY(ctx, hipMemcpyAsync(E, d + o_E, 8, hipMemcpyDeviceToHost, ctx->stream));

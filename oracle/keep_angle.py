@@ -142,18 +142,65 @@ def dihedral_energy(p, k, phi0):
     return 0.5 * k * diff * diff * s1 * s2
 
 
+def outofplane_energy(p, k, theta0):
+    """keep_outofplain_angle_potential.py:33-146; p: centre, probe, two plane atoms"""
+    a1, a2, a3 = _sub(p[1], p[0]), _sub(p[2], p[0]), _sub(p[3], p[0])
+    n = _cross(a2, a3)
+    nsq = _dot(n, n)
+    if nsq.v < 1e-8:
+        return HD(0.0)
+    inv = 1.0 / nsq.sqrt().clamp(lo=1e-12)
+    h = _dot(a1, [c * inv for c in n])
+    a1n = _dot(a1, a1).sqrt()
+    rproj = (a1n * a1n - h * h).clamp(lo=0.0).sqrt()
+    diff = atan2(h, rproj) - theta0
+    return 0.5 * k * diff * diff
+
+
+def fragment_distance_egh(X, frag1_0, frag2_0, k, r0_bohr):
+    """StructKeepPotentialv2.calc_energy (keep_potential.py:79-115) with hyper-dual derivatives: E, grad (N, 3), H (3N, 3N)."""
+    X = np.asarray(X, dtype=float).reshape(-1, 3)
+    N = X.shape[0]
+    slots = list(frag1_0) + list(frag2_0)
+    n1 = len(frag1_0)
+    nv = 3 * len(slots)
+    g = np.zeros((N, 3))
+    H = np.zeros((3 * N, 3 * N))
+    E = 0.0
+    for i in range(nv):
+        for j in range(i, nv):
+            cs = [[HD(0.0), HD(0.0), HD(0.0)], [HD(0.0), HD(0.0), HD(0.0)]]
+            for a, at in enumerate(slots):
+                f = 0 if a < n1 else 1
+                for d in range(3):
+                    cs[f][d] = cs[f][d] + HD(X[at, d], 1.0 if 3 * a + d == i else 0.0, 1.0 if 3 * a + d == j else 0.0)
+            c1 = [c * (1.0 / n1) for c in cs[0]]
+            c2 = [c * (1.0 / (len(slots) - n1)) for c in cs[1]]
+            v = _sub(c1, c2)
+            dd = _dot(v, v).sqrt().clamp(lo=1e-12) - r0_bohr
+            e = 0.5 * k * dd * dd
+            E = e.v
+            r, c = 3 * slots[i // 3] + i % 3, 3 * slots[j // 3] + j % 3
+            if i == j:
+                g[slots[i // 3], i % 3] += e.a
+            H[r, c] += e.c
+            if i != j:
+                H[c, r] += e.c
+    return E, g, H
+
+
 def deg2rad_as_reference(angle_deg):
     """torch.deg2rad(torch.tensor(angle)) of the reference (keep_angle_potential.py:71-73, keep_dihedral_angle_potential.py:77-79): a float32
     tensor, so the equilibrium angle carries single precision -- 180 degrees comes out 8.7e-8 above pi and misses the `theta_0 == pi` branch."""
     return float(np.float32(angle_deg) * np.float32(math.pi / 180.0))
 
 
-def energy_gradient_hessian(X, atoms0, k, angle_rad, dihedral=False):
+def energy_gradient_hessian(X, atoms0, k, angle_rad, dihedral=False, out_of_plane=False):
     """E, grad (N, 3), H (3N, 3N) of one term; atoms0: 0-based."""
     X = np.asarray(X, dtype=float).reshape(-1, 3)
     N = X.shape[0]
     nv = 3 * len(atoms0)
-    f = dihedral_energy if dihedral else angle_energy
+    f = outofplane_energy if out_of_plane else (dihedral_energy if dihedral else angle_energy)
     g = np.zeros((N, 3))
     H = np.zeros((3 * N, 3 * N))
     E = 0.0

@@ -1113,11 +1113,25 @@ def g14b_keep_angle():
     for phi, ph0, bend in ((1.0, 60.0, 1.9), (-2.9, 175.0, 1.9), (3.0, -170.0, 2.0), (0.3, 0.0, 1.2), (2.0, 120.0, math.pi - 6e-5), (1.2, 30.0, math.pi - 2e-5), (-1.0, -90.0, 1.7)):
         cases_.append(("dihedral", with_dihedral(phi, bend), [1, 2, 3, 4], 0.25, ph0))
     cases_.append(("dihedral", base.copy(), [2, 5, 3, 6], 0.15, 45.0))
+    # out-of-plane angles (centre, probe, two plane atoms) and fragment-centre distances
+    from multioptpy.Potential.keep_outofplain_angle_potential import StructKeepOutofPlainAnglePotential
+    from multioptpy.Potential.keep_potential import StructKeepPotentialv2
+    cases_.append(("oop", base.copy(), [1, 2, 3, 4], 0.3, 20.0))
+    cases_.append(("oop", base.copy(), [5, 2, 6, 3], 0.2, -35.0))
+    xo = base.copy()
+    xo[0] = [0.0, 0.0, 0.0]; xo[2] = [1.4, 0.0, 0.0]; xo[3] = [2.8, 3e-5, 0.0]; xo[1] = [0.3, 0.4, 1.1]        # plane atoms collinear with the centre: guard
+    cases_.append(("oop", xo, [1, 2, 3, 4], 0.3, 10.0))
+    cases_.append(("frag", base.copy(), [[1, 2, 3], [4, 5]], 0.12, 2.1))
+    cases_.append(("frag", base.copy(), [[6], [1, 2, 3, 4]], 0.2, 1.4))
     out = {"ncase": np.array(len(cases_))}
     for ci, (kind, x, atoms, k, ang) in enumerate(cases_):
         tag = f"a{ci:02d}"
         if kind == "angle":
             pot = StructKeepAnglePotential(keep_angle_spring_const=k, keep_angle_angle=ang, keep_angle_atom_pairs=atoms)
+        elif kind == "oop":
+            pot = StructKeepOutofPlainAnglePotential(keep_out_of_plain_angle_spring_const=k, keep_out_of_plain_angle_angle=ang, keep_out_of_plain_angle_atom_pairs=atoms)
+        elif kind == "frag":
+            pot = StructKeepPotentialv2(keep_pot_v2_spring_const=k, keep_pot_v2_distance=ang, keep_pot_v2_fragm1=atoms[0], keep_pot_v2_fragm2=atoms[1])
         else:
             pot = StructKeepDihedralAnglePotential(keep_dihedral_angle_spring_const=k, keep_dihedral_angle_angle=ang, keep_dihedral_angle_atom_pairs=atoms)
         xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
@@ -1126,7 +1140,8 @@ def g14b_keep_angle():
         H = torch.func.hessian(pot.calc_energy, argnums=0)(xt, [])
         out[tag + "_kind"] = np.array(kind)
         out[tag + "_x"] = x
-        out[tag + "_atoms"] = np.array(atoms)
+        out[tag + "_atoms"] = np.array(atoms if kind != "frag" else atoms[0] + atoms[1])
+        out[tag + "_n1"] = np.array(len(atoms[0]) if kind == "frag" else 0)
         out[tag + "_k"] = np.array(k)
         out[tag + "_angle_deg"] = np.array(ang)
         out[tag + "_E"] = np.array(float(E))

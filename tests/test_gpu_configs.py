@@ -593,15 +593,20 @@ def test_keep_pot_bias_vs_reference():
 
 
 def test_keep_angle_and_dihedral_bias_vs_reference():
-    """G14b: angle and dihedral-angle restraints on the device (hyper-dual evaluation of the reference's expressions: Taylor branches near
+    """G14b: angle, dihedral-angle, out-of-plane-angle and fragment-centre distance restraints on the device (hyper-dual evaluation of the reference's expressions: Taylor branches near
     0 / 180 degrees, periodic wrap, collinearity switch, the single-precision equilibrium angle) against the reference's torch autograd outputs;
     two terms in one call add up."""
     import test_oracle_golden as tog
-    from multioptpy_amd.Potential.keep_angle_potential import StructKeepAnglePotential, StructKeepDihedralAnglePotential, keep_angle_sum
+    from multioptpy_amd.Potential.keep_angle_potential import (StructKeepAnglePotential, StructKeepDihedralAnglePotential, StructKeepOutofPlainAnglePotential,
+                                                               StructKeepPotentialv2, keep_angle_sum)
 
     def fn(kind, x, atoms, k, ang):
         if kind == "angle":
             pot = StructKeepAnglePotential(keep_angle_spring_const=k, keep_angle_angle=ang, keep_angle_atom_pairs=atoms)
+        elif kind == "oop":
+            pot = StructKeepOutofPlainAnglePotential(keep_out_of_plain_angle_spring_const=k, keep_out_of_plain_angle_angle=ang, keep_out_of_plain_angle_atom_pairs=atoms)
+        elif kind == "frag":
+            pot = StructKeepPotentialv2(keep_pot_v2_spring_const=k, keep_pot_v2_distance=ang, keep_pot_v2_fragm1=atoms[0], keep_pot_v2_fragm2=atoms[1])
         else:
             pot = StructKeepDihedralAnglePotential(keep_dihedral_angle_spring_const=k, keep_dihedral_angle_angle=ang, keep_dihedral_angle_atom_pairs=atoms)
         return pot.calc_energy_gradient_hessian(x)

@@ -634,7 +634,11 @@ def _check_g14b(fn, tol):
     for i in range(int(z["ncase"])):
         tag = f"a{i:02d}"
         kind = str(z[tag + "_kind"])
-        E, g, H = fn(kind, z[tag + "_x"], [int(a) for a in z[tag + "_atoms"]], float(z[tag + "_k"]), float(z[tag + "_angle_deg"]))
+        atoms = [int(a) for a in z[tag + "_atoms"]]
+        if kind == "frag":                               # (two atom lists; the "angle" slot carries the distance in angstrom)
+            n1 = int(z[tag + "_n1"])
+            atoms = [atoms[:n1], atoms[n1:]]
+        E, g, H = fn(kind, z[tag + "_x"], atoms, float(z[tag + "_k"]), float(z[tag + "_angle_deg"]))
         refH = z[tag + "_H"]
         if not np.isfinite(refH).all():          # (torch.where multiplies the unselected branch's infinite derivative by zero: NaN in the reference itself)
             continue
@@ -647,10 +651,13 @@ def _check_g14b(fn, tol):
 
 
 def test_g14b_keep_angle_oracle_vs_reference():
-    """G14b: angle and dihedral-angle restraints (Taylor branches near 0 / 180 degrees, periodic wrap, collinearity switch) -- the oracle's
+    """G14b: angle, dihedral-angle, out-of-plane-angle and fragment-centre distance restraints (Taylor branches near 0 / 180 degrees, periodic wrap,
+    collinearity switch and guard) -- the oracle's
     hyper-dual restatement against the reference's torch.func.jacrev / hessian outputs."""
     from oracle import keep_angle as ka
 
     def fn(kind, x, atoms, k, ang):
-        return ka.energy_gradient_hessian(x, [a - 1 for a in atoms], k, ka.deg2rad_as_reference(ang), dihedral=(kind == "dihedral"))
+        if kind == "frag":
+            return ka.fragment_distance_egh(x, [a - 1 for a in atoms[0]], [a - 1 for a in atoms[1]], k, ang / 0.52917721067)
+        return ka.energy_gradient_hessian(x, [a - 1 for a in atoms], k, ka.deg2rad_as_reference(ang), dihedral=(kind == "dihedral"), out_of_plane=(kind == "oop"))
     print("oracle angle restraints vs reference: worst relative Hessian deviation", _check_g14b(fn, 1e-9))
