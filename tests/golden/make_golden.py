@@ -769,6 +769,9 @@ def g8_optmain():
     _run_optmain("c", 7, ["-opt", "rsprfo_bofill", "-order", "1", "-ns", "6", "-fc", "5"], out)
     # `-pc`: a bond and an angle kept by the constrained optimizer the dispatcher builds for crsirfo_* keys (optimizer.py:450-451)
     _run_optmain("d", 7, ["-opt", "crsirfo_bfgs", "-ns", "6", "-pc", "bond", "1,2", "angle", "3,4,5"], out)
+    # mode-following RS-I-RFO through the dispatcher (optimizer.py:438-448): Cartesian overlaps, and mass-weighted ones following mode 1
+    _run_optmain("e", 7, ["-opt", "mf_rsirfo_bofill", "-order", "1", "-ns", "6", "-fc", "5"], out)
+    _run_optmain("f", 7, ["-opt", "mwmf_rsirfo_fsb:1", "-order", "1", "-ns", "6", "-fc", "5"], out)
     np.savez_compressed(os.path.join(HERE, "g8_optmain.npz"), **out)
 
 

@@ -553,7 +553,7 @@ def test_outer_trust_radius_vs_reference():
             assert abs(tr - z[f"c{c}_tr"][k]) < 1e-12, (c, k)
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_optmain_driver_vs_reference(tag):
     """a15/a20/a23: the in-memory optmain iteration on the device path against the reference driver's own trajectory (G8):
     geometry, move vector, new geometry, Hessian, outer trust radius, displacement and convergence thresholds per iteration."""

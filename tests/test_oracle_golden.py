@@ -279,7 +279,7 @@ def _check_optmain(run, z, tag, tol):
     return worst
 
 
-@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d", "e", "f"])
 def test_g8_optmain_driver(tag):
     """a15/a20/a23: the oracle's in-memory optmain iteration against the reference driver's own trajectory (d: `-opt crsirfo_bfgs -pc bond
     1,2 angle 3,4,5` -- the constrained optimizer through the dispatcher)."""
