@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(192) k_rfo_scalar(int n, const mopt_rsirfo_par
                                                    const double *__restrict__ Be, const UpdateCoef *__restrict__ coef,
                                                    double *__restrict__ coef_out_, int dbg, const int *__restrict__ mf, int nmf) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    rfo_scalar_body<false>(n, (int)blockIdx.x, params, states, W, perm, einfo, gt_all_, Bg, Be, coef, coef_out_, dbg, sm, mf, nmf);
+    rfo_scalar_body<0>(n, (int)blockIdx.x, params, states, W, perm, einfo, gt_all_, Bg, Be, coef, coef_out_, dbg, sm, mf, nmf);
 }
 
 // out[b][j] = - sum_i coef[b][i] Vt[b][i][j]     grid (ceil(n/64), batch), block 1024: 16 waves share the rows of a

@@ -191,6 +191,7 @@ __device__ __forceinline__ double small_projgrad(int n, const double *x, const d
 }
 
 __host__ __device__ inline size_t small_r0_doubles(int n) { return (size_t)24 * n + 36 + (((size_t)3 * n + 8 + 1) / 2) + 2; }
+__host__ __device__ inline size_t small_rfo_scratch_doubles(int n) { return (((size_t)15 * n + ((size_t)3 * n + 1) / 2 + 4) + 1) & ~(size_t)1; }
 __host__ __device__ inline size_t small_aux_doubles(int n) {
     const size_t vecs = (size_t)22 * n, ch = (n + 63) / 64, tail = 5 * 64 * ch + (size_t)(n - 2) * (n - 1) / 2 + 2;
     return vecs > tail ? vecs : tail;
@@ -353,7 +354,7 @@ __device__ __forceinline__ int small_eigen(int n, int b, double *M, double *aux,
         }
         if (tid == 0) {
             const int word = (bad || nf) ? 1 : (s_fail ? 4 : 0);
-            seinfo[0] = 0; seinfo[1] = word;
+            seinfo[0] = 0; seinfo[1] = word; seinfo[2] = 0; seinfo[3] = 0;      // ([2], [3]: hand-shake words of the scalar stage)
             einfo_g[0] = 0; einfo_g[1] = word;
             if (sticky && (word & 12)) atomicOr(sticky, word & 12);
             s_flag = (bad || nf) ? 1 : 0;
@@ -558,8 +559,10 @@ __global__ void __launch_bounds__(1024) k_small_rsirfo(SmallArgs a) {
     double *sV = R1 + nn;
     SM_STAMP();
     // ================= G. scalar stage (wave 0; its barriers are wave-level)
-    if (wid == 0)
-        rfo_scalar_body<true>(n, 0, a.params + b, a.states + b, sW, sperm, seinfo, sgt, sbg, a.be + b, a.any_update ? a.coef + b : nullptr, scf, 0, R1 + 2 * nn);
+    // (waves 1 and 2 solve the two bracket problems of the step-length search next to wave 0's first solve; each wave has its own scratch)
+    if (wid < 3)
+        rfo_scalar_body<2>(n, 0, a.params + b, a.states + b, sW, sperm, seinfo, sgt, sbg, a.be + b, a.any_update ? a.coef + b : nullptr, scf, 0,
+                           R1 + 2 * nn + (size_t)wid * small_rfo_scratch_doubles(n), nullptr, 0, wid, seinfo + 2);
     lds_barrier();
     SM_STAMP();
     // ================= H. step = - sum_i coef_i v_i   (run() returns -move, rsirfo.py:490)
@@ -832,7 +835,7 @@ int mopt_launch_small_rsirfo_io(mopt_ctx *ctx, RsirfoWork &wk, int n, int batch,
     const size_t dsmall = (size_t)10 * n * 8 + (size_t)n * sizeof(DcRot) + 8 * 8 + (size_t)8 * n * 4 + 64;
     const size_t dtabs = (size_t)3 * nn * 8, dleaf = (nn + (size_t)16 * 32 * DCB_LEAF) * 8;
     const size_t pdc = (dsmall + (dtabs > dleaf ? dtabs : dleaf) + 7) / 8;
-    const size_t pf = 2 * nn + (size_t)15 * n + ((size_t)3 * n + 1) / 2 + 4;
+    const size_t pf = 2 * nn + 3 * small_rfo_scratch_doubles(n);
     size_t ph = pa;
     if (pql > ph) ph = pql;
     if (pdc > ph) ph = pdc;

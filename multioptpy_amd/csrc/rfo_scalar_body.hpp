@@ -32,18 +32,22 @@ __device__ inline bool ill_conditioned(const WaveRed &red, const double *w, int 
 // Three waves per image: all of them run the (cheap, identical) set-up; then wave 0 solves the RFO equations for alpha0 while waves 1 and 2
 // solve them for the two bracket values of alpha (1e-6, alpha_max) -- three of the five secular solves of a step side by side --
 // and wave 0 finishes alone (logic.h rs_step_rest).  dynamic LDS: 15 * n doubles + 3 * n ints
-// FUSED = false: the three waves of k_rfo_scalar's workgroup.  FUSED = true: called by ONE wave of a larger workgroup (k_small.hip); every
+// MODE 0: the three waves of k_rfo_scalar's workgroup (workgroup barriers).  MODE 1: called by ONE wave of a larger workgroup; MODE 2: called by waves
+// 0 .. 2 of a larger workgroup (k_small.hip), wave index in `wv`, each wave with its OWN scratch `sm` -- they run the same set-up side by side on the
+// shared read-only inputs, waves 1 and 2 solve the two bracket problems and raise done[0] / done[1] (LDS ints the caller has zeroed), wave 0 waits
+// for both behind its own first solve.  In modes 1 and 2 every
 // barrier of the body is then a wave-level one and the wave runs the two bracket solves itself.  sm: 15 * n doubles + 3 * n ints of LDS.
-template <bool FUSED>
+template <int MODE>
 __device__ __forceinline__ void rfo_scalar_body(int n, int b, const mopt_rsirfo_params *params, mopt_rsirfo_state *states, const double *W, const int *perm,
                                                 const int *einfo, const double *gt_all_, const double *Bg, const double *Be, const UpdateCoef *coef,
-                                                double *coef_out_, int dbg, double *sm, const int *mf = nullptr, int nmf = 0) {
+                                                double *coef_out_, int dbg, double *sm, const int *mf = nullptr, int nmf = 0, int wv = 0, int *done = nullptr) {
+    constexpr bool FUSED = MODE != 0;
     // mf != null: MF_RSIRFO (mf_rsirfo.py:128-265) -- the modes to reflect are the nmf ascending positions in mf (chosen by the mode follower on the
     // host) instead of the first saddle_order non-zero ones, and the trust-radius update takes the curvature of the first of them
     auto SYNC = [] { if constexpr (FUSED) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); };
     // one latency-bound wave per image, usually running next to the back-transformation (pipeline.hip): highest issue priority on its SIMD
     __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x & 63, wid = FUSED ? 0 : (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, wid = (MODE == 0) ? (int)(threadIdx.x >> 6) : (MODE == 2 ? wv : 0);
     __shared__ double s_n2[2];
     double *w0 = sm;             // [n] eigenvalues of the projected Hessian (ascending)
     double *g0 = w0 + n;         // [n] v_i . g in that order
@@ -214,8 +218,23 @@ __device__ __forceinline__ void rfo_scalar_body(int n, int b, const mopt_rsirfo_
         const WaveRedLocal redl;
         double lam0 = 0.0, n2_0 = 0.0;
         int its0 = 0;
-        if constexpr (FUSED) {
+        if constexpr (MODE == 1) {
             if (m > 0) rr = rs_step(redl, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw);
+        } else if constexpr (MODE == 2) {
+            if (wid != 0) {
+                if (m > 0) {
+                    double q;
+                    solve_rfo(redl, ws, gs, m, wid == 1 ? 1e-6 : p.alpha_max, stp, &q, nullptr, cg2, cw);      // (this wave's own scratch)
+                    if (lane == 0) { s_n2[wid - 1] = q; __threadfence_block(); ((volatile int *)done)[wid - 1] = 1; }
+                }
+                return;
+            }
+            if (m > 0) {
+                lam0 = solve_rfo(redl, ws, gs, m, p.alpha0, stp, &n2_0, &its0, cg2, cw);
+                while (((volatile int *)done)[0] == 0 || ((volatile int *)done)[1] == 0) __builtin_amdgcn_s_sleep(1);
+                __threadfence_block();
+                rr = rs_step_rest(redl, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw, lam0, n2_0, its0, &s_n2[0], &s_n2[1]);
+            }
         } else {
         if (m > 0) {
             if (wid == 0) lam0 = solve_rfo(redl, ws, gs, m, p.alpha0, stp, &n2_0, &its0, cg2, cw);
