@@ -65,6 +65,10 @@ int mopt_debug_occupy(mopt_ctx *ctx, double ms, int lds_bytes, int blocks);
  * synchronisation (mopt_rsirfo_run, mopt_rsprfo_run, mopt_crsirfo_run, mopt_band_download) then check the gaps and return MOPT_E_STATE,
  * naming the array in front of a damaged gap.  A read of memory nobody wrote shows up as NaN in the results. */
 int mopt_debug_poison(int enable);
+/* test aid: row at which the tridiagonalisation of each matrix of the last mopt_eigh call of this context stopped on a diagonal
+ * trailing block (0: it ran to the end, or the route has no such test); returns the number of entries written (<= cap) or a status < 0.
+ * No counterpart in the reference (numpy.linalg.eigh, rsirfo.py:606). */
+int mopt_debug_last_deflation(mopt_ctx *ctx, int *out, int cap);
 /* milliseconds spent in the named kernel family since the last reset, measured with HIP
  * events on the ctx stream when timing is enabled (bench.py roofline leg). */
 int mopt_ctx_timing(mopt_ctx *ctx, int enable);

@@ -115,6 +115,9 @@ class MF_RSIRFO(RSIRFO):
         self.last_targets = [int(t) for t in targets]
         tg = (C.c_int * 8)(*self.last_targets)
         step = np.empty((1, n))
+        between = getattr(self, "_between_halves", None)          # test hook: other library calls on this context between the halves
+        if between is not None:
+            between()
         check(lib().mopt_mf_rsirfo_finish(c, n, C.byref(p), C.byref(s), tg, len(self.last_targets), ptr(step)), c)
         self._unpack(s)
         self.prev_geometry = geom_num_list

@@ -35,6 +35,8 @@ def _proto(lib):
     if hasattr(lib, "mopt_debug_occupy"):
         lib.mopt_debug_occupy.argtypes = [vp, C.c_double, C.c_int, C.c_int]
     lib.mopt_debug_poison.argtypes = [C.c_int]
+    if hasattr(lib, "mopt_debug_last_deflation"):
+        lib.mopt_debug_last_deflation.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
     lib.mopt_ctx_timing.argtypes = [vp, C.c_int]
     lib.mopt_ctx_timing_read.argtypes = [vp, C.c_char_p, DP, C.POINTER(C.c_int64)]
     lib.mopt_hess_update.argtypes = [vp, C.c_int, C.c_int, C.c_int, DP, DP, DP, DP, DP, DP]

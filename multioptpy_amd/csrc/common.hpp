@@ -193,6 +193,7 @@ struct mopt_ctx {
                                              // (set for image-sharded bands with more than one rank: their exchange stream is a fifth busy stream of the
                                              // process, more than the default number of hardware queues, and a kernel that spins for a kernel queued behind
                                              // it on a shared queue would stall until its time-out)
+    std::vector<int> last_defl;              // mopt_eigh: where the tridiagonalisation of each matrix of the last call stopped early (0: ran to the end); mopt_debug_last_deflation
     long long n_retries = 0;                 // images solved again after a hand-off time-out (mopt_ctx_timing_read family "tri_retries")
     bool tri_no_persist = false;             // eigen-solver: take the launch-per-step tridiagonalisation (retry after a hand-off time-out)
     // early start of the leading block (k_early.hip): staging + flags (grow-only), and the D array known to hold the sentinel

@@ -26,8 +26,8 @@
 #include "dc_logic.h"
 #include "ql_block.hpp"
 
-#ifndef MOPT_P3_DEFL_TOL
-#define MOPT_P3_DEFL_TOL 2048.0  /* deflation tolerance per matrix entry in units of eps * max(|d|, |e| so far) */
+#ifndef MOPT_P3_DEFL_C
+#define MOPT_P3_DEFL_C 16.0    /* deflation budget: everything dropped by one reduction stays below C n eps max(|d|, |e|) in the Frobenius norm, see k_tri_persist3 */
 #endif
 #ifndef MOPT_P3_DEFLATE
 #define MOPT_P3_DEFLATE 1      /* early stop of the persistent tridiagonalisation on a diagonal trailing block, see k_tri_persist3 */
@@ -37,6 +37,19 @@ namespace mopt {
 
 constexpr double DEPS = 2.220446049250313e-16;
 constexpr double DTINY = 2.2250738585072014e-308;
+
+// Deflation code of a row of the trailing block (k_tri_persist3): its off-diagonal mass ss = sum_j a_ij^2 in units of (eps max|T|)^2,
+// rounded UP to a power of two: code = L + 1 with 2^L >= ss / unit^2 (L = 0 for anything below one unit); 0 = not finite / beyond the
+// representable range, never counted as diagonal.
+__device__ __forceinline__ unsigned defl_code(double ss, double unit) {
+    if (!(unit > 0.0)) return ss == 0.0 ? 1u : 0u;
+    const double r = (ss / unit) / unit;
+    if (!(r <= 1.0e60)) return 0u;                           // (also NaN)
+    if (r <= 1.0) return 1u;
+    int e;
+    (void)frexp(r, &e);                                      // r = m 2^e with m in [0.5, 1): r < 2^e
+    return (unsigned)(e + 1);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024) k_tridiag(int n, int dbg, double *__restrict__ A_, double *__restrict__ D_, double *__restrict__ E_,
@@ -1079,13 +1092,26 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     // Deflation (round 3).  Hessians of quasi-Newton runs are identity (or a model matrix) + low rank: after m + 1 Householder steps the
     // Krylov space of the first unit vector is exhausted, the pivot row's tail is rounding noise and the trailing block is diagonal to
     // working precision -- the remaining n - m steps would build reflectors from noise.  Test, at no cost for dense matrices:
-    //   * a pivot-row tail with |x|^2 <= (n - lo) tol^2, tol = 8 eps max(|d|, |e| so far), counts as zero (no reflector, tau = 0);
-    //   * in the main pass of such a step every row wave also takes the largest |a_ij| over its live off-diagonal entries and sends
-    //     "<= tol" as a flag in the top byte of its p value's second tag word;
-    //   * wave 0 of every member sees all flags in the next prologue: if every live row is diagonal (and no reflector is pending: tau = 0),
-    //     all members stop at this step -- every row owner stores D = a_ii, E = 0, TAU = 0 for its rows.
-    // Dropping entries <= 8 eps ||T|| perturbs eigenvalues by a few 1e-15 ||T||, the size of the split criterion of k_tri_bisect.
+    //   * a pivot-row tail x with |x|^2 <= C^2 n u^2, u = eps max(|d|, |e| so far), counts as zero (no reflector, tau = 0) while the BUDGET
+    //     below allows it;
+    //   * in the main pass of such a step every row wave also takes the sum of squares of its live off-diagonal entries and sends it,
+    //     rounded up to a power of two in units of u^2 (defl_code), in the top byte of its p value's second tag word;
+    //   * wave 0 of every member sees all codes in the next prologue: a row counts as diagonal when its code is <= C^2 n; if every live row
+    //     is diagonal (and no reflector is pending: tau = 0) and the budget allows it, all members stop at this step -- every row owner
+    //     stores D = a_ii, E = 0, TAU = 0 for its rows.
+    // Budget (round 4): the reduction keeps the sum of squares of everything it has dropped so far (`dropped`: pivot-row tails
+    // twice -- row and column --, the codes' upper bounds of the rows a stop or a jump passes over) and drops only while
+    //     sqrt(dropped) <= C n eps max(|d|, |e|),      C = MOPT_P3_DEFL_C = 16,
+    // i.e. the tridiagonal form returned is that of A + E with ||E||_F <= C n eps ||T||_max whatever the distribution of the entries:
+    // a norm-wise bound of the kind LAPACK's dsytrd carries for its own rounding (c n eps ||A||), instead of the per-entry tolerance of
+    // 2048 eps of round 3, whose worst case was ~1450 n eps ||A||.  A few straggling entries well above 16 eps no longer end the early
+    // stop -- what decides is their total mass; once the budget is used up the reduction goes on exactly.  Every member takes the same
+    // decisions from the same words (the prologue is redundant and deterministic).
     double dmax = 0.0;                                       // (wave 0) largest |d|, |e| so far
+    double dropped = 0.0;                                    // (wave 0) sum of squares of everything dropped so far (absolute units)
+    double chk_unit = 0.0;                                   // (wave 0) the unit u the row waves were given for their codes
+    unsigned capb = 1u;                                      // largest code that still counts as diagonal: 2^(capb - 1) <= C^2 n
+    { const double cm = MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n; while (capb < 200u && ldexp(1.0, (int)capb) <= cm) ++capb; }
     bool chk_prev = false;                                   // (wave 0) the previous step asked for the flags
     int defl_at = -1;                                        // first row of the diagonal trailing block when the reduction stopped early
     int nsteps = 0;
@@ -1133,7 +1159,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                     const bool need = (jj >= lo) & (jj < n);
                     const bool got = (xr[q][1] == tag) & (xr[q][3] == tag) & ((k < 0) | ((xp[q][1] == tag) & ((xp[q][3] & 0x00FFFFFFu) == tag)));
                     ok = ok & (got | !need);
-                    if constexpr (DEFL) cand = (need & ((xp[q][3] >> 24) != 1u) & (jj < cand)) ? jj : cand;      // first live row of this lane without the "diagonal" flag
+                    if constexpr (DEFL) { const unsigned cb = xp[q][3] >> 24; cand = (need & ((cb == 0u) | (cb > capb)) & (jj < cand)) ? jj : cand; }      // first live row of this lane that is not diagonal
                 }
 #ifdef MOPT_P3_ABL_NOWAIT
                 ok = true;                                   // (timing ablation: one load pass, no waiting; results are garbage)
@@ -1156,6 +1182,21 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                         if (((kk - k) & 1) == 0) --kk;
                         if (kk >= k + 3) kj = kk;
                     }
+                }
+                if (all_diag || kj >= 0) {
+                    // the budget: upper bounds of the off-diagonal masses of the rows passed over (stop: every entry is in two of the rows;
+                    // jump: the columns of the passed rows inside the rows that stay are dropped with them, hence twice)
+                    const int rend = all_diag ? n : kj + 1;
+                    double ml = 0.0;
+#pragma unroll
+                    for (int q = Q0; q < CH; ++q) {
+                        const int jj = lane + 64 * q;
+                        if (jj >= lo && jj < rend) ml += ldexp(1.0, (int)(xp[q][3] >> 24) - 1);
+                    }
+                    const double mass = wave_sum(ml) * chk_unit * chk_unit * (all_diag ? 1.0 : 2.0);
+                    const double bud = MOPT_P3_DEFL_C * (double)n * DEPS * dmax;
+                    if (dropped + mass <= bud * bud) dropped += mass;
+                    else { all_diag = false; kj = -1; }
                 }
             }
             // (the prologue below runs in either case: row lo carries the flag, so its tail is negligible, no reflector comes out of it and
@@ -1198,9 +1239,14 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             const double alpha = lane_bcast(al_l, (lo + 1) & 63);
             const double diag = lane_bcast(dg_l, lo & 63);
             dmax = fmax(dmax, fmax(fabs(diag), (lo + 1 < n) ? fabs(alpha) : 0.0));
-            const double tolv = MOPT_P3_DEFL_TOL * DEPS * dmax;
-            const int ntail = n - lo - 2;
-            const bool tiny = DEFL && MOPT_P3_DEFLATE && (xn2 <= tolv * tolv * (double)(ntail > 1 ? ntail : 1));
+            const bool special = all_diag || kj >= 0;        // stop or jump: the step has no main pass (and row lo's tail is part of what was charged)
+            const double unit = DEPS * dmax;
+            bool tiny = false;
+            if constexpr (DEFL && MOPT_P3_DEFLATE) {
+                const double bud = MOPT_P3_DEFL_C * (double)n * unit;
+                tiny = special || (xn2 <= MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n * unit * unit && dropped + 2.0 * xn2 <= bud * bud);
+                if (tiny && !special) dropped += 2.0 * xn2;  // (row and column)
+            }
             const bool refl = (lo <= n - 3 && xn2 != 0.0 && !tiny);
             const double bt = -copysign(sqrt(alpha * alpha + xn2), alpha);
             const double betan = refl ? bt : alpha;
@@ -1213,10 +1259,9 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 svn[jj] = vn;
             }
             dmax = fmax(dmax, fabs(betan));
-            const bool special = all_diag || kj >= 0;        // stop or jump: the step has no main pass
             chk_prev = DEFL && MOPT_P3_DEFLATE && (lo <= n - 3) && !refl && !special;      // no reflector from this pivot row: is the trailing block diagonal already?
             if (lane == 0) {
-                if constexpr (DEFL) { s_chk[nxt & 1] = chk_prev ? tolv : -1.0; s_jump[nxt & 1] = kj; if (all_diag) s_defl = 1; }
+                if constexpr (DEFL) { s_chk[nxt & 1] = chk_prev ? unit : -1.0; s_jump[nxt & 1] = kj; if (all_diag) s_defl = 1; }
                 if (special) {
                     // the pivot row's owner may have left the kernel already (the pivot has reached its last row): its D, E, TAU are stored
                     // here, by every member the same numbers (taun = 0)
@@ -1230,6 +1275,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 if (g == 0 || lo + 1 >= last_row0) { double *mb = s_mail + 4 * (nxt & 1); mb[0] = diag; mb[1] = betan; mb[2] = taun; }
             }
             tau = taun;
+            chk_unit = unit;
             }
             if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
         } else if (prof) t0 = wall_clock64();
@@ -1286,10 +1332,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                     }
                     unsigned flag = 0u;
                     if (DEFL && chkv >= 0.0) {
-                        double mx = 0.0;
+                        double ss = 0.0;
 #pragma unroll
-                        for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(areg[t][q]) : 0.0); }
-                        flag = (wave_max(mx) <= chkv) ? 1u : 0u;
+                        for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; const double av = ((jj > lo) & (jj < n) & (jj != gi)) ? areg[t][q] : 0.0; ss = fma(av, av, ss); }
+                        flag = defl_code(wave_sum(ss), chkv);
                     }
                     const double d0 = wave_sum63(d0v[t]);
                     if (lane == 63) { if (xlocs) put16f<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); else put16f<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); }
@@ -1327,10 +1373,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                         }
                         unsigned flag = 0u;
                         if (DEFL && chkv >= 0.0) {                                      // (rare, wave-uniform) largest live off-diagonal entry of the row
-                            double mx = 0.0;
+                            double ss = 0.0;
 #pragma unroll
-                            for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(areg[t][q]) : 0.0); }
-                            flag = (wave_max(mx) <= chkv) ? 1u : 0u;
+                            for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; const double av = ((jj > lo) & (jj < n) & (jj != gi)) ? areg[t][q] : 0.0; ss = fma(av, av, ss); }
+                            flag = defl_code(wave_sum(ss), chkv);
                         }
 #ifndef MOPT_P3_ABL_NORED
                         d0 = wave_sum63(d0);                                            // total in lane 63
@@ -1367,10 +1413,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                     }
                     unsigned flag = 0u;
                     if (DEFL && chkv >= 0.0) {
-                        double mx = 0.0;
+                        double ss = 0.0;
 #pragma unroll
-                        for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) mx = fmax(mx, ((jj > lo) & (jj < n) & (jj != gi)) ? fabs(a[q]) : 0.0); }
-                        flag = (wave_max(mx) <= chkv) ? 1u : 0u;
+                        for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) { const double av = ((jj > lo) & (jj < n) & (jj != gi)) ? a[q] : 0.0; ss = fma(av, av, ss); } }
+                        flag = defl_code(wave_sum(ss), chkv);
                     }
                     d0 = wave_sum63(d0);
                     if (lane == 63) { if (xlocs) put16f<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); else put16f<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); }

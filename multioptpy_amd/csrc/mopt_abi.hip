@@ -384,7 +384,9 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     if (n < 1 || batch < 1 || n > MOPT_MAX_N || !A || !W || !V) { ctx->err = "mopt_eigh: bad arguments"; return MOPT_E_ARG; }
     hipSetDevice(ctx->device);
     const size_t nn = (size_t)batch * n * n * sizeof(double), nv = (size_t)batch * n * sizeof(double);
-    DBuf dA, dG, dVt, dV, dsig, drot, dW, dperm, dinfo;
+    DBuf dA, dG, dVt, dV, dsig, drot, dW, dperm, dinfo, ddefl;
+    TRY(ddefl.alloc(ctx, (size_t)batch * sizeof(int)));
+    ctx->last_defl.clear();
     TRY(dA.alloc(ctx, nn)); TRY(dG.alloc(ctx, nn + (size_t)batch * MOPT_TRI_T_DOUBLES(n) * sizeof(double))); TRY(dVt.alloc(ctx, nn)); TRY(dV.alloc(ctx, nn));
     TRY(dsig.alloc(ctx, batch * sizeof(double))); TRY(drot.alloc(ctx, (size_t)batch * (JAC_MAX_SWEEPS + 1) * sizeof(int)));
     TRY(dW.alloc(ctx, nv)); TRY(dperm.alloc(ctx, (size_t)batch * n * sizeof(int))); TRY(dinfo.alloc(ctx, (size_t)batch * 2 * sizeof(int)));
@@ -394,6 +396,7 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
     // which needs no co-residency -- a busy GPU is not a numerical failure.
     for (int attempt = 0; attempt < 2; ++attempt) {
         H2D(ctx, dA.p, A, nn);
+        MOPT_HIP_TRY(ctx, hipMemsetAsync(ddefl.p, 0, (size_t)batch * sizeof(int), ctx->stream));
         if (mopt_eigh_algo(n) == 1) {
             DBuf dsc, dsi;
             const size_t nvi = (size_t)batch * n;
@@ -404,8 +407,10 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
             if (attempt == 1) ctx->tri_no_persist = true;
             const int rc = mopt_launch_eigh_tridiag(ctx, n, batch, dA.as<double>(), dVt.as<double>(), sc, sc + nvi, sc + 2 * nvi, sc + 3 * nvi, sc + 4 * nvi,
                                                     si, si + nvi, si + 2 * nvi, si + 4 * nvi, si + 4 * nvi + 2 * batch, dW.as<double>(), dperm.as<int>(),
-                                                    dinfo.as<int>(), dG.as<double>());
+                                                    dinfo.as<int>(), dG.as<double>(), nullptr, nullptr, ddefl.as<int>(), -1);
             ctx->tri_no_persist = saved;
+            ctx->last_defl.assign(batch, 0);
+            if (rc == MOPT_OK) D2H(ctx, ctx->last_defl.data(), ddefl.p, (size_t)batch * sizeof(int));
             ctx->early_clean = nullptr;                      // (the scratch of this call is freed below: k_tri_early's sentinel bookkeeping is per address)
             if (rc != MOPT_OK) return rc;
             MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -429,6 +434,15 @@ extern "C" int mopt_eigh(mopt_ctx *ctx, int n, int batch, const double *A, doubl
             return MOPT_E_NUMERIC;
         }
     return MOPT_OK;
+}
+
+// test aid: where the tridiagonalisation of each matrix of the last mopt_eigh call on this context stopped early (row index; 0 = it ran
+// to the end or took a route without the test).  Returns the number of entries written, or a negative status.
+extern "C" int mopt_debug_last_deflation(mopt_ctx *ctx, int *out, int cap) {
+    if (!ctx || !out || cap < 0) return MOPT_E_ARG;
+    const int m = (int)ctx->last_defl.size() < cap ? (int)ctx->last_defl.size() : cap;
+    for (int i = 0; i < m; ++i) out[i] = ctx->last_defl[i];
+    return m;
 }
 
 extern "C" int mopt_dgemm(mopt_ctx *ctx, int n, int batch, const double *A, const double *B, double *C) {
@@ -540,7 +554,10 @@ static int ws_get(mopt_ctx *ctx, int n, int batch, bool own_h, bool bias, bool i
 
 // ---- MF_RSIRFO in two halves (include/mopt_hip.h) ---------------------------------------------------------------------------------
 namespace {
-struct MfPending { RsirfoWork *wk = nullptr; RsirfoWork *own = nullptr; int n = 0; bool any_upd = false; bool valid = false; };
+// The workspace between the two halves belongs to the pending record, not to the shape cache above: a single-geometry call on the same
+// context between begin and finish (same shape: it would overwrite eigw / Vt / perm; another shape: it may evict the entry) cannot
+// touch it.  It is kept from call to call while the shape stays the same.
+struct MfPending { RsirfoWork *own = nullptr; int n = 0, flags = 0; bool any_upd = false; bool valid = false; };
 std::map<mopt_ctx *, MfPending> g_mf;
 std::mutex g_mf_mu;
 void mf_drop(MfPending &p) { if (p.own) delete p.own; p = MfPending(); }
@@ -559,19 +576,22 @@ extern "C" int mopt_mf_rsirfo_begin(mopt_ctx *ctx, int n, const mopt_rsirfo_para
     if (!hessian) { ctx->err = "Hessian matrix must be set"; return MOPT_E_STATE; }
     if (params->rule < 0 || params->rule >= MOPT_RULE_COUNT) { ctx->err = "unknown update rule"; return MOPT_E_ARG; }
     hipSetDevice(ctx->device);
-    MfPending *pend;
-    { std::lock_guard<std::mutex> lk(g_mf_mu); pend = &g_mf[ctx]; mf_drop(*pend); }
-    RsirfoWork *wkp = nullptr;
-    if (mopt_debug_poison_on()) {
+    std::lock_guard<std::mutex> lk(g_mf_mu);                // held for the whole call: the record is not shared between threads half-way
+    MfPending *pend = &g_mf[ctx];
+    pend->valid = false;
+    const int wflags = (bias_hessian ? 2 : 0) | (H_inplace ? 4 : 0);
+    if (pend->own && (pend->n != n || pend->flags != wflags || mopt_debug_poison_on())) {
+        hipStreamSynchronize(ctx->stream);
+        mf_drop(*pend);
+    }
+    if (!pend->own) {
         pend->own = new (std::nothrow) RsirfoWork();
         if (!pend->own) return MOPT_E_NOMEM;
-        TRY(pend->own->alloc(ctx, n, 1, true, bias_hessian != nullptr, H_inplace != nullptr));
-        wkp = pend->own;
-    } else {
-        void *io = nullptr;
-        TRY(ws_get(ctx, n, 1, true, bias_hessian != nullptr, H_inplace != nullptr, 256, &wkp, &io));
+        const int rc = pend->own->alloc(ctx, n, 1, true, bias_hessian != nullptr, H_inplace != nullptr);
+        if (rc != MOPT_OK) { mf_drop(*pend); return rc; }
+        pend->n = n; pend->flags = wflags;
     }
-    RsirfoWork &wk = *wkp;
+    RsirfoWork &wk = *pend->own;
     const size_t nn = (size_t)n * n * sizeof(double), nv = (size_t)n * sizeof(double);
     const int upd = (pre_geom && pre_g && state->has_prev) ? 1 : 0, rule = params->rule;
     H2D(ctx, wk.x, geom, nv); H2D(ctx, wk.bg, B_g, nv); H2D(ctx, wk.g, g ? g : B_g, nv);
@@ -612,7 +632,7 @@ extern "C" int mopt_mf_rsirfo_begin(mopt_ctx *ctx, int n, const mopt_rsirfo_para
         for (int i = 0; i < n; ++i) V_out[(size_t)k * n + i] = ident ? (i == k ? 1.0 : 0.0) : vt[(size_t)r * n + i];
     }
     if (hess_updated) *hess_updated = upd ? hc.applied : 0;
-    pend->wk = wkp; pend->n = n; pend->any_upd = upd != 0; pend->valid = true;
+    pend->any_upd = upd != 0; pend->valid = true;
     return MOPT_OK;
 }
 
@@ -620,11 +640,11 @@ extern "C" int mopt_mf_rsirfo_finish(mopt_ctx *ctx, int n, const mopt_rsirfo_par
                                      double *step) {
     if (bad_dims(ctx, n, 1)) return MOPT_E_ARG;
     if (!params || !state || !step || ntargets < 0 || ntargets > 8 || (ntargets > 0 && !targets)) { ctx->err = "mopt_mf_rsirfo_finish: bad argument"; return MOPT_E_ARG; }
-    MfPending *pend;
-    { std::lock_guard<std::mutex> lk(g_mf_mu); pend = &g_mf[ctx]; }
-    if (!pend->valid || pend->n != n || !pend->wk) { ctx->err = "mopt_mf_rsirfo_finish without a matching mopt_mf_rsirfo_begin"; return MOPT_E_STATE; }
+    std::lock_guard<std::mutex> lk(g_mf_mu);
+    MfPending *pend = &g_mf[ctx];
+    if (!pend->valid || pend->n != n || !pend->own) { ctx->err = "mopt_mf_rsirfo_finish without a matching mopt_mf_rsirfo_begin"; return MOPT_E_STATE; }
     hipSetDevice(ctx->device);
-    RsirfoWork &wk = *pend->wk;
+    RsirfoWork &wk = *pend->own;
     int tg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int t = 0; t < ntargets; ++t) tg[t] = targets[t];
     H2D(ctx, wk.params, params, sizeof(mopt_rsirfo_params));
@@ -638,8 +658,7 @@ extern "C" int mopt_mf_rsirfo_finish(mopt_ctx *ctx, int n, const mopt_rsirfo_par
     MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     pend->valid = false;
     int rc = MOPT_OK;
-    if (mopt_debug_poison_on()) rc = wk.check_canaries();
-    { std::lock_guard<std::mutex> lk(g_mf_mu); if (pend->own) { delete pend->own; pend->own = nullptr; pend->wk = nullptr; } }
+    if (mopt_debug_poison_on()) { rc = wk.check_canaries(); mf_drop(*pend); }
     if (rc != MOPT_OK) return rc;
     if (st.jacobi_sweeps < 0) { ctx->err = "mopt_mf_rsirfo_finish: the eigen-solver failed"; return MOPT_E_NUMERIC; }
     *state = st;

@@ -50,15 +50,94 @@ def test_diagonal_and_block_diagonal_inputs():
     _check(np.stack([A0, A1, A2, A3]))
 
 
-def test_noise_level_coupling_is_dropped_not_amplified():
-    """Identity + low rank + symmetric noise of 1e-17: below the deflation tolerance (8 eps ||T||), so the reduction stops early; the
-    eigenvalues must still agree with LAPACK to 1e-13 ||A||.  And noise of 1e-12 -- above the tolerance -- must be resolved (no stop)."""
+DEFL_C = 16.0            # MOPT_P3_DEFL_C of k_tridiag.hip
+EPS = 2.220446049250313e-16
+
+
+def _last_deflation(batch):
+    import ctypes as C
+    from multioptpy_amd import _lib
+    out = (C.c_int * batch)()
+    m = _lib.lib().mopt_debug_last_deflation(_lib.ctx(), out, batch)
+    assert m == batch, m
+    return np.array(list(out))
+
+
+def test_deflation_budget_noise_below_and_above():
+    """The early stop drops at most C n eps max|T| in the Frobenius norm (C = 16, k_tri_persist3 "Budget").  Identity + rank-12 + symmetric
+    noise at three levels, each derived from that bound with max|T| <= ||A||_2:
+      * 1e-17 (rounding level) and a noise matrix whose whole Frobenius norm is 1 / 16 of the budget of the SMALLEST possible max|T| seen at
+        the stop (the identity part's 1): the reduction must stop early in every matrix;
+      * a noise matrix whose trailing block alone carries 20 x the budget of the LARGEST possible max|T| (||A||_2): provably above the
+        threshold -- no matrix may stop (mopt_debug_last_deflation == 0), the noise is resolved as data.
+    Eigenvalues against LAPACK at 1e-13 ||A|| in all three."""
     rng = np.random.default_rng(21)
-    n = 300
-    for lvl in (1e-17, 1e-12):
-        N = rng.normal(size=(n, n)) * lvl
-        A = np.stack([_low_rank(n, 12, rng) + 0.5 * (N + N.T) for _ in range(8)])
-        _check(A)
+    n, batch = 300, 8
+    base = [_low_rank(n, 12, rng) for _ in range(batch)]
+    a2 = max(np.abs(np.linalg.eigvalsh(B)).max() for B in base)
+    sig_sym = np.sqrt(0.5)                                   # std of the off-diagonal entries of 0.5 (N + N^T), N ~ N(0, 1)
+    lvl_lo = DEFL_C * n * EPS * 1.0 / 16.0 / (sig_sym * n)
+    lvl_hi = 20.0 * DEFL_C * n * EPS * a2 / (sig_sym * (n - 40))
+    for lvl, must_stop in ((1e-17, True), (lvl_lo, True), (lvl_hi, False)):
+        A = []
+        for B in base:
+            N = rng.normal(size=(n, n)) * lvl
+            A.append(B + 0.5 * (N + N.T))
+        _check(np.stack(A))
+        d = _last_deflation(batch)
+        if must_stop:
+            assert (d > 0).all() and (d < n // 2).all(), (lvl, d)
+        else:
+            assert (d == 0).all(), (lvl, d)
+        print(f"noise {lvl:.2e}: reduction stopped at rows {d.tolist()}")
+
+
+def test_deflation_stragglers_are_charged_not_counted():
+    """A handful of couplings far above any per-entry tolerance (1e-11: 45 000 eps) deep inside the identity block: their total mass is what
+    counts.  Eight entries of 1e-13 stay inside the budget (stop or jump over them), eight entries of 1e-9 do not (they are resolved: those
+    rows get reflectors).  Either way the eigenvalues agree with LAPACK."""
+    rng = np.random.default_rng(5)
+    n = 256
+    for val in (1e-13, 1e-9):
+        A = []
+        for b in range(4):
+            B = _low_rank(n, 6 + b, rng, scale=0.5)
+            for t in range(8):
+                i, j = 100 + 17 * t, 101 + 17 * t + b
+                B[i, j] += val; B[j, i] += val
+            A.append(B)
+        _check(np.stack(A))
+        print(f"stragglers of {val:.0e}: reduction stopped at rows {_last_deflation(4).tolist()}")
+
+
+def test_stiff_and_soft_spectrum_small_eigenvalues():
+    """Stiff low-rank part (||.|| ~ 1e2) on a SOFT multiple of the identity (1e-4 .. 1e-3): the regime in which a loose absolute tolerance
+    would cost the small eigenvalues their digits.  The n - r soft eigenvalues are known exactly (c); the error of the device's values
+    must stay within the documented bound C n eps ||A||_2 and within a small multiple of LAPACK's own error on the same matrix; the
+    stiff ones agree relatively."""
+    rng = np.random.default_rng(77)
+    n, r = 300, 10
+    from multioptpy_amd import ops
+    for c in (1e-4, 1e-3):
+        U = np.linalg.qr(rng.normal(size=(n, r)))[0]
+        lam = np.concatenate([rng.uniform(20.0, 120.0, r // 2), -rng.uniform(20.0, 120.0, r - r // 2)])
+        A = c * np.eye(n) + (U * lam) @ U.T
+        A = 0.5 * (A + A.T)
+        w, v = ops.eigh(A)
+        wl = np.linalg.eigvalsh(A)
+        a2 = np.abs(wl).max()
+        soft = np.abs(w) < 1.0
+        assert soft.sum() == n - r
+        err_dev = np.abs(w[soft] - c).max()
+        err_lap = np.abs(wl[np.abs(wl) < 1.0] - c).max()
+        bound = DEFL_C * n * EPS * a2
+        assert err_dev <= bound, (c, err_dev, bound)
+        assert err_dev <= max(8.0 * err_lap, 16 * EPS * a2), (c, err_dev, err_lap)
+        stiff_exact = np.sort(lam + c)
+        assert np.abs(np.sort(w[~soft]) - stiff_exact).max() <= 64 * n * EPS * a2
+        res = np.abs(A @ v - v * w).max()
+        assert res < 5e-12 * a2
+        print(f"soft level {c:g}: device error of the soft eigenvalues {err_dev:.2e} (relative {err_dev / c:.1e}), LAPACK {err_lap:.2e}, bound {bound:.2e}; stopped at row {_last_deflation(1).tolist()}")
 
 
 def test_band_long_run_identity_start_vs_oracle():

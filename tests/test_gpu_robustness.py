@@ -106,6 +106,37 @@ def test_poisoned_workspace_mf_rsirfo_and_small_kernels_general_path():
         _lib.lib().mopt_debug_poison(0)
 
 
+def test_mf_rsirfo_halves_survive_other_calls_on_the_context():
+    """between mopt_mf_rsirfo_begin and _finish the workspace must not be reachable by other single-geometry calls of the same
+    context.  Every MF_RSIRFO.run of the G15 traces gets, between its halves, an RSIRFO.run of the SAME n (a same-shape hit of the
+    workspace cache used to overwrite eigw / Vt / perm) and runs of five other sizes (more shapes than the cache holds: eviction used to
+    free the pending workspace).  The traces must still equal the reference's."""
+    from multioptpy_amd.Optimizer.mf_rsirfo import MF_RSIRFO
+    from multioptpy_amd.Optimizer.rsirfo import RSIRFO
+    import test_oracle_golden as tog
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g15_mf_rsirfo.npz"))
+    calls = [0]
+
+    def disturb(n_same):
+        for N in (n_same // 3, 27, 29, 31, 37, 41):
+            x = cases.cluster(N)
+            E, G, H = cases.lj(x, hessian=True)
+            o = RSIRFO(method="rsirfo_bfgs", saddle_order=0)
+            o.set_hessian(H.copy())
+            o.set_bias_hessian(np.zeros_like(H))
+            o.run(x.reshape(-1, 1), G.reshape(-1, 1), [], [], E, 0.0, [], [], G.reshape(-1, 1), [])
+            calls[0] += 1
+
+    def make(method, so, elems, masses, kw):
+        o = MF_RSIRFO(method=method, saddle_order=so, element_list=elems, **kw)
+        o._between_halves = lambda: disturb(int(np.asarray(o.hessian).shape[0]))
+        return o
+
+    worst = tog._check_mf(z, make, 1e-8)
+    assert calls[0] > 0
+    print("MF_RSIRFO with", calls[0], "foreign calls between the halves: worst step deviation from the reference", worst)
+
+
 def test_poison_mode_detects_an_out_of_bounds_write():
     """The checker itself: a deliberately oversized copy into a band array (through the public upload call with a forged image count is
     not possible, so the test corrupts a gap with hipMemset through the runtime) must be reported as MOPT_E_STATE."""
