@@ -50,6 +50,8 @@ __global__ void k_set_gnorm(mopt_rsprfo_state *st, const double *gn) { st[0].gra
 // outcome of the checked update (rsprfo.py:1236-1250) without a host round trip: flag = 0 no update applied, 1 accepted (the bound
 // ||candidate||_inf / 1.0625 <= 1e6 holds, so max |eig| <= 1e6 does too), 2 the spectrum itself has to be looked at (the caller repeats
 // the call through the path that does)
+// (sigma NaN / Inf: `<= 1e6` is false -> flag 2 -> the general path computes the spectrum and applies the reference's own test, which accepts a
+// non-finite candidate because `NaN > 1e6` is False, rsprfo.py:1246-1255 with numpy 2.2)
 __global__ void k_prfo_accept(const UpdateCoef *__restrict__ coef, const double *__restrict__ sigma, int *__restrict__ flag) {
     flag[0] = coef[0].applied ? ((sigma[0] / 1.0625 <= 1e6) ? 1 : 2) : 0;
 }

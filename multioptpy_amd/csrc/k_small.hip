@@ -742,6 +742,8 @@ __global__ void __launch_bounds__(1024) k_small_rsprfo(SmallPrfoArgs a) {
             lds_barrier();
             double mx = 0.0;
             for (int w_ = 0; w_ < 16; ++w_) mx = fmax(mx, s_red[w_]);
+            // (a non-finite candidate is ACCEPTED, as by the reference: numpy 2.2's eigvalsh returns NaNs for it without raising -- checked in
+            // the build container --, `max_eigval > 1e6` is then False and rsprfo.py:1255 takes the new matrix; ADVICE r03 asked)
             const bool need_spectrum = (mx > 0.0 && isfinite(mx)) && !(mx <= 1e6);
             if (need_spectrum) {
                 if (tid == 0) { a.flags[3] = 2; __threadfence_system(); if (a.done) __hip_atomic_fetch_add(a.done, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }

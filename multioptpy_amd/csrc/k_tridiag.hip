@@ -41,10 +41,12 @@ constexpr double DTINY = 2.2250738585072014e-308;
 // Deflation code of a row of the trailing block (k_tri_persist3): its off-diagonal mass ss = sum_j a_ij^2 in units of (eps max|T|)^2,
 // rounded UP to a power of two: code = L + 1 with 2^L >= ss / unit^2 (L = 0 for anything below one unit); 0 = not finite / beyond the
 // representable range, never counted as diagonal.
-__device__ __forceinline__ unsigned defl_code(double ss, double unit) {
-    if (!(unit > 0.0)) return ss == 0.0 ? 1u : 0u;
-    const double r = (ss / unit) / unit;
-    if (!(r <= 1.0e60)) return 0u;                           // (also NaN)
+// `cap`: rows whose mass exceeds it (a row counts as diagonal up to C^2 n units) report 0 as well.
+// (inv = 1 / unit^2, formed once by wave 0 -- no division in the row waves, whose main pass sets the kernel's register count; 1e300 for
+// a matrix that has been all zero so far: any non-zero entry then counts as not diagonal)
+__device__ __forceinline__ unsigned defl_code(double ss, double inv, double cap) {
+    const double r = ss * inv;
+    if (!(r <= cap)) return 0u;                              // (also NaN)
     if (r <= 1.0) return 1u;
     int e;
     (void)frexp(r, &e);                                      // r = m 2^e with m in [0.5, 1): r < 2^e
@@ -1003,6 +1005,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ int s_fail, s_xloc, s_defl, s_jump[2];       // s_defl: stop (trailing block diagonal); s_jump[2]: >= 0 jump to that step
     __shared__ double s_mail[8];                             // [2][4] D, E, TAU of a step on their way to the storing wave
+    __shared__ double s_dacc[2];                             // deflation budget bookkeeping of wave 0, see "Budget" below
     __shared__ double s_chk[2];                              // [2] deflation test of a step: tolerance (>= 0) or -1 = no test, see "Deflation" below
     long long t_poll = 0, t_pro = 0, t_main = 0, t_bar = 0, t0 = 0, t1 = 0;
     const long long c_start = prof ? clock64() : 0, w_start = prof ? wall_clock64() : 0;
@@ -1017,7 +1020,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     double *D = D_ + (size_t)b * n, *E = E_ + (size_t)b * n, *TAU = TAU_ + (size_t)b * n;
     u64 *PX = XCH_ + (size_t)b * xch_stride;                // [2][n][2]
     u64 *ROWX = PX + (size_t)4 * n;                         // [2][n][2]
-    if (tid == 0) { s_fail = 0; s_defl = 0; s_chk[0] = -1.0; s_chk[1] = -1.0; s_jump[0] = -1; s_jump[1] = -1; }
+    if (tid == 0) { s_fail = 0; s_defl = 0; s_dacc[0] = 0.0; s_dacc[1] = 0.0; s_chk[0] = -1.0; s_chk[1] = -1.0; s_jump[0] = -1; s_jump[1] = -1; }
     for (int i = tid; i < 5 * NS; i += blockDim.x) sm[i] = 0.0;
     int r_end = 0;
     for (int r = 0; r < rows_cap; ++r) r_end += ((g + (r / TRI_RC) * G) * TRI_RC + (r % TRI_RC) < n) ? 1 : 0;
@@ -1095,8 +1098,8 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     //   * a pivot-row tail x with |x|^2 <= C^2 n u^2, u = eps max(|d|, |e| so far), counts as zero (no reflector, tau = 0) while the BUDGET
     //     below allows it;
     //   * in the main pass of such a step every row wave also takes the sum of squares of its live off-diagonal entries and sends it,
-    //     rounded up to a power of two in units of u^2 (defl_code), in the top byte of its p value's second tag word;
-    //   * wave 0 of every member sees all codes in the next prologue: a row counts as diagonal when its code is <= C^2 n; if every live row
+    //     rounded up to a power of two in units of u^2 (defl_code; 0 when it exceeds C^2 n), in the top byte of its p value's second tag word;
+    //   * wave 0 of every member sees all codes in the next prologue: a row counts as diagonal when its code is not 0; if every live row
     //     is diagonal (and no reflector is pending: tau = 0) and the budget allows it, all members stop at this step -- every row owner
     //     stores D = a_ii, E = 0, TAU = 0 for its rows.
     // Budget (round 4): the reduction keeps the sum of squares of everything it has dropped so far (`dropped`: pivot-row tails
@@ -1108,10 +1111,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
     // stop -- what decides is their total mass; once the budget is used up the reduction goes on exactly.  Every member takes the same
     // decisions from the same words (the prologue is redundant and deterministic).
     double dmax = 0.0;                                       // (wave 0) largest |d|, |e| so far
-    double dropped = 0.0;                                    // (wave 0) sum of squares of everything dropped so far (absolute units)
-    double chk_unit = 0.0;                                   // (wave 0) the unit u the row waves were given for their codes
-    unsigned capb = 1u;                                      // largest code that still counts as diagonal: 2^(capb - 1) <= C^2 n
-    { const double cm = MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n; while (capb < 200u && ldexp(1.0, (int)capb) <= cm) ++capb; }
+    // (wave 0; kept in LDS -- s_dacc[0]: sum of squares of everything dropped so far in absolute units, s_dacc[1]: the unit u the row waves
+    // were given for their codes -- because they are touched on the rare paths only and the kernel has to stay within 116 registers per
+    // lane for the early-start watcher, k_early.hip, to fit beside it)
+
     bool chk_prev = false;                                   // (wave 0) the previous step asked for the flags
     int defl_at = -1;                                        // first row of the diagonal trailing block when the reduction stopped early
     int nsteps = 0;
@@ -1159,7 +1162,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                     const bool need = (jj >= lo) & (jj < n);
                     const bool got = (xr[q][1] == tag) & (xr[q][3] == tag) & ((k < 0) | ((xp[q][1] == tag) & ((xp[q][3] & 0x00FFFFFFu) == tag)));
                     ok = ok & (got | !need);
-                    if constexpr (DEFL) { const unsigned cb = xp[q][3] >> 24; cand = (need & ((cb == 0u) | (cb > capb)) & (jj < cand)) ? jj : cand; }      // first live row of this lane that is not diagonal
+                    if constexpr (DEFL) cand = (need & ((xp[q][3] >> 24) == 0u) & (jj < cand)) ? jj : cand;      // first live row of this lane that is not diagonal (code 0)
                 }
 #ifdef MOPT_P3_ABL_NOWAIT
                 ok = true;                                   // (timing ablation: one load pass, no waiting; results are garbage)
@@ -1186,16 +1189,21 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 if (all_diag || kj >= 0) {
                     // the budget: upper bounds of the off-diagonal masses of the rows passed over (stop: every entry is in two of the rows;
                     // jump: the columns of the passed rows inside the rows that stay are dropped with them, hence twice)
+                    // (the codes are fetched once more -- the words are final, their tags were checked above -- instead of being kept in
+                    // registers behind the poll loop: this path is taken a few times per reduction, the registers would be held in every step)
+                    // (summed in integers on the scalar unit -- ballots per code value -- for the same reason: one vector register)
                     const int rend = all_diag ? n : kj + 1;
-                    double ml = 0.0;
-#pragma unroll
-                    for (int q = Q0; q < CH; ++q) {
-                        const int jj = lane + 64 * q;
-                        if (jj >= lo && jj < rend) ml += ldexp(1.0, (int)(xp[q][3] >> 24) - 1);
+                    unsigned long long msum = 0ull;
+                    for (int j0 = lo; j0 < rend; j0 += 64) {
+                        const int jj = j0 + lane;
+                        unsigned cb = 0u;
+                        if (jj < rend) cb = __builtin_amdgcn_raw_buffer_load_b32(rsP, (cur * n + jj) * 16 + 12, 0, 16) >> 24;
+                        for (unsigned bv = 1u; bv <= 40u; ++bv) msum += (unsigned long long)__popcll(__ballot(cb == bv)) << (bv - 1u);
                     }
-                    const double mass = wave_sum(ml) * chk_unit * chk_unit * (all_diag ? 1.0 : 2.0);
+                    const double cu = s_dacc[1], dr = s_dacc[0];
+                    const double mass = (double)msum * cu * cu * (all_diag ? 1.0 : 2.0);
                     const double bud = MOPT_P3_DEFL_C * (double)n * DEPS * dmax;
-                    if (dropped + mass <= bud * bud) dropped += mass;
+                    if (dr + mass <= bud * bud) s_dacc[0] = dr + mass;      // (every lane stores the same number: no lane reads what only another one wrote)
                     else { all_diag = false; kj = -1; }
                 }
             }
@@ -1243,9 +1251,11 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             const double unit = DEPS * dmax;
             bool tiny = false;
             if constexpr (DEFL && MOPT_P3_DEFLATE) {
-                const double bud = MOPT_P3_DEFL_C * (double)n * unit;
-                tiny = special || (xn2 <= MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n * unit * unit && dropped + 2.0 * xn2 <= bud * bud);
-                if (tiny && !special) dropped += 2.0 * xn2;  // (row and column)
+                tiny = special;
+                if (!special && xn2 <= MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n * unit * unit) {      // (rare for dense matrices)
+                    const double bud = MOPT_P3_DEFL_C * (double)n * unit, dr = s_dacc[0] + 2.0 * xn2;     // (row and column)
+                    if (dr <= bud * bud) { tiny = true; s_dacc[0] = dr; }
+                }
             }
             const bool refl = (lo <= n - 3 && xn2 != 0.0 && !tiny);
             const double bt = -copysign(sqrt(alpha * alpha + xn2), alpha);
@@ -1260,8 +1270,10 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             }
             dmax = fmax(dmax, fabs(betan));
             chk_prev = DEFL && MOPT_P3_DEFLATE && (lo <= n - 3) && !refl && !special;      // no reflector from this pivot row: is the trailing block diagonal already?
+            double chk_inv = -1.0;
+            if constexpr (DEFL) { if (chk_prev) { s_dacc[1] = unit; chk_inv = (unit > 1e-150) ? (1.0 / unit) / unit : 1e300; } }
             if (lane == 0) {
-                if constexpr (DEFL) { s_chk[nxt & 1] = chk_prev ? unit : -1.0; s_jump[nxt & 1] = kj; if (all_diag) s_defl = 1; }
+                if constexpr (DEFL) { s_chk[nxt & 1] = chk_inv; s_jump[nxt & 1] = kj; if (all_diag) s_defl = 1; }
                 if (special) {
                     // the pivot row's owner may have left the kernel already (the pivot has reached its last row): its D, E, TAU are stored
                     // here, by every member the same numbers (taun = 0)
@@ -1275,7 +1287,6 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 if (g == 0 || lo + 1 >= last_row0) { double *mb = s_mail + 4 * (nxt & 1); mb[0] = diag; mb[1] = betan; mb[2] = taun; }
             }
             tau = taun;
-            chk_unit = unit;
             }
             if (prof) { t1 = wall_clock64(); t_pro += t1 - t0; t0 = t1; }
         } else if (prof) t0 = wall_clock64();
@@ -1335,7 +1346,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                         double ss = 0.0;
 #pragma unroll
                         for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; const double av = ((jj > lo) & (jj < n) & (jj != gi)) ? areg[t][q] : 0.0; ss = fma(av, av, ss); }
-                        flag = defl_code(wave_sum(ss), chkv);
+                        flag = defl_code(wave_sum(ss), chkv, MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n);
                     }
                     const double d0 = wave_sum63(d0v[t]);
                     if (lane == 63) { if (xlocs) put16f<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); else put16f<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); }
@@ -1376,7 +1387,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                             double ss = 0.0;
 #pragma unroll
                             for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; const double av = ((jj > lo) & (jj < n) & (jj != gi)) ? areg[t][q] : 0.0; ss = fma(av, av, ss); }
-                            flag = defl_code(wave_sum(ss), chkv);
+                            flag = defl_code(wave_sum(ss), chkv, MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n);
                         }
 #ifndef MOPT_P3_ABL_NORED
                         d0 = wave_sum63(d0);                                            // total in lane 63
@@ -1416,7 +1427,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                         double ss = 0.0;
 #pragma unroll
                         for (int q = Q0; q < CH; ++q) { const int jj = lane + 64 * q; if (q < chn) { const double av = ((jj > lo) & (jj < n) & (jj != gi)) ? a[q] : 0.0; ss = fma(av, av, ss); } }
-                        flag = defl_code(wave_sum(ss), chkv);
+                        flag = defl_code(wave_sum(ss), chkv, MOPT_P3_DEFL_C * MOPT_P3_DEFL_C * (double)n);
                     }
                     d0 = wave_sum63(d0);
                     if (lane == 63) { if (xlocs) put16f<true>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); else put16f<false>(rsP, (nxt * n + gi) * 16, d0, tag + 1u, flag); }

@@ -736,12 +736,16 @@ static int rsirfo_run_small(mopt_ctx *ctx, int n, int batch, const mopt_rsirfo_p
         }
         if (!seen) MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
+    // a failed image is looked for BEFORE anything is copied out: on MOPT_E_NUMERIC the caller's state, step and Hessians stay as they were
+    {
+        const mopt_rsirfo_state *ps = (const mopt_rsirfo_state *)(pin + o_st);
+        for (int b = 0; b < batch; ++b)
+            if (ps[b].jacobi_sweeps < 0) { ctx->err = "mopt_rsirfo_run: the eigen-solver failed"; return MOPT_E_NUMERIC; }
+    }
     std::memcpy(state, pin + o_st, batch * sizeof(mopt_rsirfo_state));
     std::memcpy(step, pin + o_step, nv);
     if (H_sym) std::memcpy(H_sym, pin + o_Hs, nn);
     if (H_inplace) std::memcpy(H_inplace, pin + o_Hp, nn);
-    for (int b = 0; b < batch; ++b)
-        if (state[b].jacobi_sweeps < 0) { ctx->err = "mopt_rsirfo_run: the eigen-solver failed"; return MOPT_E_NUMERIC; }
     return MOPT_OK;
 }
 

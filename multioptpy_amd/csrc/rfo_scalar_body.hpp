@@ -140,8 +140,12 @@ __device__ __forceinline__ void rfo_scalar_body(int n, int b, const mopt_rsirfo_
     //   moved t (t-th in index order):               rank = #{unmoved u : val_u <= val_t} + #{t' < t : val_t' <= val_t} + #{t' > t : val_t' < val_t}
     int m = 0;
     int *srt = kidx + n;                 // [n] index at sorted position
-    __shared__ int s_moved[8];
-    __shared__ int s_nmoved;
+    // (MODE 2: three waves run this set-up side by side, each on its own scratch -- the list of moved entries lives there too, in the `ex`
+    // area that only MODE 0 uses, so that no wave reads what another one is writing)
+    __shared__ int s_moved_wg[8];
+    __shared__ int s_nmoved_wg;
+    int *const s_moved = (MODE == 2) ? (int *)ex : s_moved_wg;
+    int &s_nmoved = (MODE == 2) ? ((int *)ex)[8] : s_nmoved_wg;
     {
         // moved entries, in index order (at most 8 are honoured, as before)
         int off = 0;
@@ -222,19 +226,16 @@ __device__ __forceinline__ void rfo_scalar_body(int n, int b, const mopt_rsirfo_
             if (m > 0) rr = rs_step(redl, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw);
         } else if constexpr (MODE == 2) {
             if (wid != 0) {
-                if (m > 0) {
-                    double q;
-                    solve_rfo(redl, ws, gs, m, wid == 1 ? 1e-6 : p.alpha_max, stp, &q, nullptr, cg2, cw);      // (this wave's own scratch)
-                    if (lane == 0) { s_n2[wid - 1] = q; __threadfence_block(); ((volatile int *)done)[wid - 1] = 1; }
-                }
+                double q = 0.0;
+                if (m > 0) solve_rfo(redl, ws, gs, m, wid == 1 ? 1e-6 : p.alpha_max, stp, &q, nullptr, cg2, cw);      // (this wave's own scratch)
+                // (raised in every case: wave 0 does not write states[b] before both of the others have read it and are done)
+                if (lane == 0) { s_n2[wid - 1] = q; __threadfence_block(); ((volatile int *)done)[wid - 1] = 1; }
                 return;
             }
-            if (m > 0) {
-                lam0 = solve_rfo(redl, ws, gs, m, p.alpha0, stp, &n2_0, &its0, cg2, cw);
-                while (((volatile int *)done)[0] == 0 || ((volatile int *)done)[1] == 0) __builtin_amdgcn_s_sleep(1);
-                __threadfence_block();
-                rr = rs_step_rest(redl, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw, lam0, n2_0, its0, &s_n2[0], &s_n2[1]);
-            }
+            if (m > 0) lam0 = solve_rfo(redl, ws, gs, m, p.alpha0, stp, &n2_0, &its0, cg2, cw);
+            while (((volatile int *)done)[0] == 0 || ((volatile int *)done)[1] == 0) __builtin_amdgcn_s_sleep(1);
+            __threadfence_block();
+            if (m > 0) rr = rs_step_rest(redl, p, st.trust_radius, ws, gs, m, stp, best, cg2, cw, lam0, n2_0, its0, &s_n2[0], &s_n2[1]);
         } else {
         if (m > 0) {
             if (wid == 0) lam0 = solve_rfo(redl, ws, gs, m, p.alpha0, stp, &n2_0, &its0, cg2, cw);

