@@ -54,6 +54,10 @@ constexpr int DC_MAXIT = 80;
 
 // number of halving levels so that every leaf has at most DC_LEAF rows; leaf boundaries lb(i) = (i n) >> L
 MOPT_DC_HD inline int dc_levels(int n) { int L = 0; while (((n + (1 << L) - 1) >> L) > DC_LEAF) ++L; return L; }
+// the same with leaves of at most DC_LEAF_WG rows, each solved by one workgroup with the in-LDS divide and conquer of dc_block_body.hpp
+// (round 4: one level of the launch-per-stage chain less -- n = 300: 8 leaves of 37 / 38 rows instead of 16 of 18 / 19)
+constexpr int DC_LEAF_WG = 40;
+MOPT_DC_HD inline int dc_levels_wg(int n) { int L = 0; while (((n + (1 << L) - 1) >> L) > DC_LEAF_WG) ++L; return L; }
 MOPT_DC_HD inline int dc_bound(int n, int L, int i) { return (int)(((long long)i * n) >> L); }
 
 struct DcRot { int a, b; double c, s; };               // rows a, b of the eigenvector table: x_a' = c x_a + s x_b, x_b' = c x_b - s x_a

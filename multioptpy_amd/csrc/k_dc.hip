@@ -21,6 +21,7 @@
 #include "dc_logic.h"
 #include "ql_block.hpp"
 #include "dc_red.hpp"
+#include "dc_block_body.hpp"
 
 namespace mopt {
 
@@ -109,6 +110,19 @@ __global__ void __launch_bounds__(64) k_dc_leaf(int n, int L, DcPtrs p, double *
         double *row = X_ + ((size_t)b * n + s + c) * n;
         for (int i = lane; i < n; i += WAVE) row[i] = (i >= s && i < t) ? Zs[c * 32 + (i - s)] : 0.0;
     }
+}
+
+// Leaves of up to DC_LEAF_WG rows by the divide and conquer inside one workgroup (dc_block_body.hpp: leaves of <= 10 rows by the one-wave
+// QL side by side, two merge levels in LDS) -- 85 us for the 8 x 32 leaves of 37 / 38 rows of a 32 x 300 batch where the one-wave QL
+// took 112 us for 18 / 19-row leaves, and the chain behind it has one level (five launches, 65 us) less.
+// grid (2^L, B), block 1024, dynamic LDS as for k_dc_block with mcap = the largest leaf.  Writes dv[s .. t) and rows s .. t-1 of X (zero outside the leaf).
+__global__ void __launch_bounds__(1024) k_dc_leaf_wg(int n, int L, DcPtrs p, double *__restrict__ dv_, double *__restrict__ X_, int *__restrict__ fail_) {
+    extern __shared__ __attribute__((aligned(16))) double smleaf[];
+    const int b = blockIdx.y;
+    if (!p.flag[b]) return;
+    const int s = dc_bound(n, L, blockIdx.x), t = dc_bound(n, L, blockIdx.x + 1), m = t - s;
+    const size_t o = (size_t)b * n + s;
+    dc_block_body(n, s, m, b, p.D2 + o, p.E2 + o, dv_ + (size_t)b * n, X_ + (size_t)b * n * n, fail_ + b, smleaf, 0);
 }
 
 // grid (n, B): zero row blockIdx.x of X for flagged matrices
@@ -427,6 +441,9 @@ __global__ void __launch_bounds__(256) k_dc_final(int n, DcPtrs p, const double 
 
 }  // namespace mopt
 
+// levels of the launch-per-stage chain for n rows (for the launch count of the timing scope)
+int mopt_dc_chain_levels(int n) { return mopt::dc_levels(n); }      // (upper bound: the workgroup leaves save a level)
+
 size_t mopt_dc_scratch_bytes(int n, int batch) {
     const size_t nv = (size_t)batch * n;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -439,7 +456,11 @@ size_t mopt_dc_scratch_bytes(int n, int batch) {
 int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_D, const double *d_E, int *d_flag, double *d_WT,
                    double *d_Vt, double *d_Z2, int *d_bstart, int *d_bend, int *d_fail, void *scratch) {
     using namespace mopt;
-    const int L = dc_levels(n);
+    static const bool leaf_ql = getenv("MOPT_DC_LEAFQL") != nullptr;      // developer switch: the one-wave QL leaves of round 2
+    // (workgroup leaves while all of them are resident at once -- two per CU --: 64 x 600 would need 1024 workgroups of 1024 threads in four
+    // rounds, 2.45 instead of 2.28 ms for its chain; its 2048 one-wave leaves run side by side)
+    const bool leaf_wave = leaf_ql || ((size_t)batch << dc_levels_wg(n)) > (size_t)2 * ctx->num_cu;
+    const int L = leaf_wave ? dc_levels(n) : dc_levels_wg(n);
     if (L < 1) return MOPT_OK;
     const size_t nv = (size_t)batch * n;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -460,7 +481,18 @@ int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double
     X[1] = (L % 2 == 0) ? d_Z2 : d_Vt;
     double *dv[2] = {p.d0, p.d1};
     hipLaunchKernelGGL(k_dc_setup, dim3(batch), dim3(256), 0, st, n, L, d_D, d_E, p, d_bstart, d_bend);
-    hipLaunchKernelGGL(k_dc_leaf, dim3(1 << L, batch), dim3(64), 0, st, n, L, p, dv[0], X[0], d_fail);
+    if (leaf_wave) hipLaunchKernelGGL(k_dc_leaf, dim3(1 << L, batch), dim3(64), 0, st, n, L, p, dv[0], X[0], d_fail);
+    else {
+        int mcap = 0;
+        for (int q = 0; q < (1 << L); ++q) { const int m = dc_bound(n, L, q + 1) - dc_bound(n, L, q); mcap = m > mcap ? m : mcap; }
+        // (the layout of dc_block_body: small arrays, then X0 + max(X1 + S, the 16 leaf tables))
+        const size_t small = (size_t)10 * mcap * 8 + (size_t)mcap * sizeof(DcRot) + 8 * 8 + (size_t)8 * mcap * 4 + 64;
+        const size_t tabs = (size_t)3 * mcap * mcap * 8, leaf = ((size_t)mcap * mcap + (size_t)16 * 32 * DCB_LEAF) * 8;
+        const size_t lds = small + (tabs > leaf ? tabs : leaf);
+        if (mcap > DCB_MAX || lds > (size_t)ctx->lds_limit - 1024) { ctx->err = "k_dc_leaf_wg: leaf too large for the LDS"; return MOPT_E_ARG; }
+        if (lds > 48000) MOPT_HIP_TRY(ctx, hipFuncSetAttribute((const void *)k_dc_leaf_wg, hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 1024));
+        hipLaunchKernelGGL(k_dc_leaf_wg, dim3(1 << L, batch), dim3(1024), lds, st, n, L, p, dv[0], X[0], d_fail);
+    }
     hipLaunchKernelGGL(k_dc_zero, dim3(n, batch), dim3(256), 0, st, n, (const int *)d_flag, X[1]);
     for (int lev = 1; lev <= L; ++lev) {
         const int nm = 1 << (L - lev);

@@ -1300,6 +1300,11 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         }
         if (prof) { t1 = wall_clock64(); t_bar += t1 - t0; t0 = t1; }
         // ---- main pass: rank-2 update of the live rows with (v, w), then p_i = row_i . v' reduced inside the wave
+        // (Measured dead end, round 4: the "lazy" order -- p_i = row_i(before the update) . v' - v_i (w . v') - w_i (v . v') with the two dot
+        // products from the prologue, one multiply-add per entry in front of the publication and the update of the row behind it -- loses:
+        // 32 x 300 dense 0.62 -> 0.71 ms, 64 x 600 band 6.50 -> 7.52 ms for the tridiagonalisation.  Wave 0 owns rows too and its deferred
+        // update sits in front of its next poll; the prologue grows by two reductions; and the update and the product as separate loops
+        // cost the 8-wave form its register allocation (27 -> 73 spilled registers).)
         if constexpr (TR > 0 && NWV == 8) {
             // 8-wave form (large row tiles: up to TR * CH = 50 doubles per lane): the column operands are taken in two groups of chunks,
             // so that only half of v, w, v' is live in registers next to the tile; the row sums are completed over both groups first
@@ -2373,6 +2378,7 @@ size_t mopt_dc_scratch_bytes(int n, int batch);
 int mopt_dc_block_max();
 int mopt_launch_dc_block(mopt_ctx *ctx, hipStream_t st, int n, int batch, int mmin, int mmax, const double *d_D, const double *d_E, const int *d_bstart,
                          const int *d_bend, double *d_WT, double *d_Zt, int *d_fail, const int *d_dcflag, const double *d_stage, const int *d_early);
+int mopt_dc_chain_levels(int n);
 int mopt_launch_dc(mopt_ctx *ctx, hipStream_t st, int n, int batch, const double *d_D, const double *d_E, int *d_flag, double *d_WT,
                    double *d_Vt, double *d_Z2, int *d_bstart, int *d_bend, int *d_fail, void *scratch);
 
@@ -2807,7 +2813,7 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
     if (d_dcflag) {
         // divide and conquer for the flagged matrices, the whole chain on its own helper stream (its kernels return at once for
         // the others; k_tri_clusters / k_tri_invit / k_tri_lowdin on the main stream do the same for the flagged ones)
-        mopt_scope scd(ctx, "eigh_dc", 4 + 5 * mopt::dc_levels(n), ctx->side3);      // (helper stream: overlaps the main-stream families)
+        mopt_scope scd(ctx, "eigh_dc", 4 + 5 * mopt_dc_chain_levels(n), ctx->side3);      // (helper stream: overlaps the main-stream families)
         const int rc = mopt_launch_dc(ctx, ctx->side3, n, batch, d_D, d_E, d_dcflag, d_WT, d_Vt, d_Z2, d_bstart, d_bend, d_fail,
                                       (char *)ctx->arena + 256);
         if (rc != MOPT_OK) return rc;
