@@ -409,6 +409,14 @@ int mopt_model_hessian(mopt_ctx *ctx, int kind, int N, int batch, const double *
 enum { MOPT_MODEL_FLAG_CLIP = 1 };
 int mopt_model_hessian_ex(mopt_ctx *ctx, int kind, int flags, int N, int batch, const double *X, const double *par, const double *d3, const double *G,
                           int project, double *H);
+/* The `sr` modifier of ApproxHessian.main (approx_hessian.py:100-102 -> ShortRangeCorrectionHessian.main, ModelHessian/shortrange.py:311-346): the
+ * short-range Coulomb pair terms of all non-bonded atom pairs (1.1 x covalent radii, 15 bohr cut-off), TR/rot-projected on their own, added to
+ * H, symmetrised, NaN -> 0.  X: batch x N x 3 (bohr); cov: N covalent radii (bohr); chg: N charges (shortrange.py:147-186); prm: omega, cx_sr,
+ * scaling factor, cut-off (the reference's defaults 0.2, 0.78, 0.5, 15.0); H: batch x 3N x 3N, in and out.  Host pointers. */
+int mopt_model_hessian_sr(mopt_ctx *ctx, int N, int batch, const double *X, const double *cov, const double *chg, const double *prm, double *H);
+/* The `clip` modifier on its own (approx_hessian.py:104-120): H <- V smooth(lambda) V^T for batch n x n host matrices, in place -- for the
+ * combinations in which another modifier comes between the model and the clipping (the reference's order is ts, sr, clip). */
+int mopt_hessian_clip(mopt_ctx *ctx, int n, int batch, double *H);
 /* The same for the owned images of a band, from the geometries last uploaded, straight into the band's Hessians in HBM
  * (the reference recomputes the model every -mfc band steps and hands it over in tmp_hessian_{i}.npy, neb.py:515-523). */
 int mopt_band_model_hessian(mopt_band *band, int kind, const double *par, const double *d3);

@@ -7,8 +7,10 @@ coordination-number scaled D3 pairs (``fischerd3``, ModelHessian/fischerd3.py:17
 ModelHessian/fischer.py:216-236), Schlegel's model (``schlegel``, ModelHessian/schlegel.py:66-144), the Morse model (``morse``,
 ModelHessian/morse.py:50-106) and Lindh's 2007 model with D3 dispersion (``lindh2007d3``, ModelHessian/lindh2007d3.py:777-822) -- which is
 also what a name the dispatcher does not know falls back to, as in the reference (approx_hessian.py:88-91) -- and the ``clip`` modifier
-(approx_hessian.py:104-120).  The Swart, Lindh-1995 / -D2 / -D4, Schlegel-D3/D4, Fischer-D4 and GFN models and the ``sr``
-modifier raise NotImplementedError (``ts``: round 3, eigen-solve on the device); there is no CPU fallback.
+(approx_hessian.py:104-120).  The Swart, Lindh-1995 / -D2 / -D4, Schlegel-D3/D4, Fischer-D4 and GFN models raise NotImplementedError; there
+is no CPU fallback.  Modifiers, in the reference's order (approx_hessian.py:95-110): ``ts`` (tshess.py: eigen-solve on the device, rank-two
+correction on the host array), ``sr`` (shortrange.py: ``mopt_model_hessian_sr``, round 4), ``clip`` (inside the model call when it is the only
+modifier, ``mopt_hessian_clip`` behind the others).
 
 Per-element parameters (covalent radii, C6, van-der-Waals radii, r4/r2, D3 scaling) are the numbers the reference's
 ``multioptpy/Parameters`` functions return, kept as data in ``element_tables.json`` (tools/extract_element_tables.py)."""
@@ -23,7 +25,13 @@ from .._lib import lib, check, f64, ptr
 
 MODEL_FISCHERD3OLD, MODEL_FISCHERD3, MODEL_FISCHER, MODEL_SCHLEGEL, MODEL_MORSE, MODEL_LINDH2007D3 = 0, 1, 2, 3, 4, 5
 FLAG_CLIP = 1
-FLAG_TS = 2          # (host-side flag of this module: the `ts` modifier; never passed to the C ABI)
+FLAG_TS = 2          # (host-side flags of this module: the `ts` and `sr` modifiers; never passed to the C ABI)
+FLAG_SR = 4
+# Pauling electronegativities as ShortRangeCorrectionHessian.estimate_atomic_charges tabulates them (shortrange.py:160-172; anything else: 2.0)
+_PAULING = {"H": 2.20, "He": 0.00, "Li": 0.98, "Be": 1.57, "B": 2.04, "C": 2.55, "N": 3.04, "O": 3.44, "F": 3.98, "Ne": 0.00, "Na": 0.93, "Mg": 1.31,
+            "Al": 1.61, "Si": 1.90, "P": 2.19, "S": 2.58, "Cl": 3.16, "Ar": 0.00, "K": 0.82, "Ca": 1.00, "Sc": 1.36, "Ti": 1.54, "V": 1.63, "Cr": 1.66,
+            "Mn": 1.55, "Fe": 1.83, "Co": 1.88, "Ni": 1.91, "Cu": 1.90, "Zn": 1.65, "Ga": 1.81, "Ge": 2.01, "As": 2.18, "Se": 2.55, "Br": 2.96, "Kr": 0.00}
+SR_PARAMS = (0.2, 0.78, 0.5, 15.0)      # omega (1/bohr), cx_sr, scaling factor, cut-off (bohr): shortrange.py:19-34
 _TAB = None
 
 
@@ -107,15 +115,45 @@ def model_kind(approx_hess_type, with_flags=False):
                                   "fischer, schlegel, morse, lindh2007d3)")
     flags = 0
     # approx_hessian.py:93-110: modifiers applied after the model, in the order ts, sr, clip (the tests see the whole name)
-    if "sr" in name:
-        raise NotImplementedError("model Hessian modifier 'sr' (short-range correction, ModelHessian/shortrange.py) is not available on the device")
     if "ts" in name:
         flags |= FLAG_TS
+    if "sr" in name:
+        flags |= FLAG_SR
     if "clip" in name:
-        if flags & FLAG_TS:
-            raise NotImplementedError("model Hessian modifiers 'ts' and 'clip' together are not available on the device")
         flags |= FLAG_CLIP
     return (kind, flags) if with_flags else kind
+
+
+def sr_charges(element_list):
+    """estimate_atomic_charges (shortrange.py:147-186): 0.2 (mean electronegativity - electronegativity), the mean as sum / len of the list"""
+    en = [_PAULING.get(str(e), 2.0) for e in element_list]
+    avg = sum(en) / len(en)
+    q = np.zeros(len(en))
+    for i, v in enumerate(en):
+        q[i] = 0.2 * (avg - v)
+    return q
+
+
+def sr_correction(H, coords, element_list, device=None):
+    """ShortRangeCorrectionHessian.main on the device for one (3N, 3N) or a batch (I, 3N, 3N) of Hessians; returns new arrays."""
+    Hc = np.array(H, dtype=np.float64, order="C")
+    X = f64(coords).reshape(-1, len(element_list), 3)
+    B, N = X.shape[0], X.shape[1]
+    cov = np.array([_tables()["elements"][str(e)]["cov"] for e in element_list], dtype=np.float64)
+    chg = sr_charges(element_list)
+    prm = np.array(SR_PARAMS, dtype=np.float64)
+    c = _lib.ctx(device)
+    check(lib().mopt_model_hessian_sr(c, N, B, ptr(X), ptr(cov), ptr(chg), ptr(prm), ptr(Hc)), c)
+    return Hc
+
+
+def clip_modification(H, device=None):
+    """The `clip` modifier behind another modifier (approx_hessian.py:104-110): V smooth(lambda) V^T on the device."""
+    Hc = np.array(H, dtype=np.float64, order="C")
+    n = Hc.shape[-1]
+    c = _lib.ctx(device)
+    check(lib().mopt_hessian_clip(c, n, int(Hc.size // (n * n)), ptr(Hc)), c)
+    return Hc
 
 
 def ts_modification(H):
@@ -149,9 +187,14 @@ class ApproxHessian:
         G = None if cart_gradient is None else f64(cart_gradient).reshape(-1, 3)
         H = np.empty((3 * N, 3 * N))
         c = _lib.ctx(self.device)
-        check(lib().mopt_model_hessian_ex(c, kind, flags & FLAG_CLIP, N, 1, ptr(X), ptr(par), ptr(d3), ptr(G), 1, ptr(H)), c)
+        later = flags & (FLAG_TS | FLAG_SR)                   # another modifier stands between the model and the clipping
+        check(lib().mopt_model_hessian_ex(c, kind, 0 if later else (flags & FLAG_CLIP), N, 1, ptr(X), ptr(par), ptr(d3), ptr(G), 1, ptr(H)), c)
         if flags & FLAG_TS:
             H = ts_modification(H)
+        if flags & FLAG_SR:
+            H = sr_correction(H, X, element_list, self.device)
+        if later and (flags & FLAG_CLIP):
+            H = clip_modification(H, self.device)
         return H
 
     def batch(self, coords, element_list, approx_hess_type="fischerd3old", project=True, cart_gradients=None):
@@ -163,8 +206,13 @@ class ApproxHessian:
         G = None if cart_gradients is None else f64(cart_gradients).reshape(I, N, 3)
         H = np.empty((I, 3 * N, 3 * N))
         c = _lib.ctx(self.device)
-        check(lib().mopt_model_hessian_ex(c, kind, flags & FLAG_CLIP, N, I, ptr(X), ptr(par), ptr(d3), ptr(G), 1 if project else 0, ptr(H)), c)
+        later = flags & (FLAG_TS | FLAG_SR)
+        check(lib().mopt_model_hessian_ex(c, kind, 0 if later else (flags & FLAG_CLIP), N, I, ptr(X), ptr(par), ptr(d3), ptr(G), 1 if project else 0, ptr(H)), c)
         if flags & FLAG_TS:
             for i in range(I):
                 H[i] = ts_modification(H[i])
+        if flags & FLAG_SR:
+            H = sr_correction(H, X, element_list, self.device)
+        if later and (flags & FLAG_CLIP):
+            H = clip_modification(H, self.device)
         return H

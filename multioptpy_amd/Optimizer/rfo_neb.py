@@ -118,7 +118,7 @@ class RFOOptimizer:
         self._have_files = True                                  # (every image's Hessian is "saved" behind the step, rfo_neb.py:175)
         self.band.upload(X, E, G)
         if self._pending_model is not None:
-            self.band.model_hessian(*self._pending_model)
+            self.band.model_hessian(*self._pending_model, coords=X, gradients=G)
             self._pending_model = None
         self.band.step(optimize_num)
         newX, F = self.band.download(want_force=True)

@@ -35,6 +35,9 @@ def _proto(lib):
     if hasattr(lib, "mopt_debug_occupy"):
         lib.mopt_debug_occupy.argtypes = [vp, C.c_double, C.c_int, C.c_int]
     lib.mopt_debug_poison.argtypes = [C.c_int]
+    if hasattr(lib, "mopt_model_hessian_sr"):
+        lib.mopt_model_hessian_sr.argtypes = [vp, C.c_int, C.c_int, DP, DP, DP, DP, DP]
+        lib.mopt_hessian_clip.argtypes = [vp, C.c_int, C.c_int, DP]
     if hasattr(lib, "mopt_debug_last_deflation"):
         lib.mopt_debug_last_deflation.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
     lib.mopt_ctx_timing.argtypes = [vp, C.c_int]

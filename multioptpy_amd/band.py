@@ -59,11 +59,25 @@ class Band:
         E = f64(E).reshape(self.I)
         check(lib().mopt_band_upload(self._h, ptr(X), ptr(E), ptr(G)), self._ctx)
 
-    def model_hessian(self, element_list, approx_hess_type="fischerd3old"):
+    def model_hessian(self, element_list, approx_hess_type="fischerd3old", coords=None, gradients=None):
         """Replace the Hessians of the owned images by the model Hessian of the geometries last uploaded, on the device
-        (neb.py:515-523 with the tmp_hessian_i.npy hand-over removed)."""
-        from .ModelHessian.approx_hessian import element_parameters, model_kind
+        (neb.py:515-523 with the tmp_hessian_i.npy hand-over removed).  Names with the `ts` or `sr` modifier (host-array steps between the
+        model and the clipping) go through ApproxHessian().batch and set_hessian instead and need the images' coordinates (I or count, N, 3;
+        bohr) and gradients."""
+        from .ModelHessian.approx_hessian import element_parameters, model_kind, FLAG_CLIP, ApproxHessian
         kind, flags = model_kind(approx_hess_type, with_flags=True)
+        if flags & ~FLAG_CLIP:
+            if coords is None:
+                raise NotImplementedError("band-resident model Hessians take the `clip` modifier only; for `ts` / `sr` pass coords (and gradients)")
+            Xc = f64(coords).reshape(-1, self.N, 3)
+            Gc = None if gradients is None else f64(gradients).reshape(-1, self.N, 3)
+            if Xc.shape[0] == self.I and self.count != self.I:
+                Xc = Xc[self.first:self.first + self.count]
+                Gc = None if Gc is None else Gc[self.first:self.first + self.count]
+            Hs = ApproxHessian().batch(Xc, element_list, approx_hess_type, cart_gradients=Gc)
+            for k in range(self.count):
+                self.set_hessian(self.first + k, Hs[k])
+            return
         par, d3 = element_parameters(element_list, kind)
         check(lib().mopt_band_model_hessian_ex(self._h, kind, flags, ptr(par), ptr(d3)), self._ctx)
 

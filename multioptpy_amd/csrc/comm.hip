@@ -53,8 +53,11 @@ bool rccl_load() {
     // library then shares) is taken first: two RCCL copies on two HIP builds in one process is the configuration to avoid.
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
     void *h = nullptr;
-    for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD); if (h) break; }
-    if (!h) for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    // (RTLD_LOCAL: when this library has to bring RCCL in itself and PyTorch is imported LATER, PyTorch loads its own copy next to it; with
+    // a global load the second copy's rocm_smi globals were bound to the first one's and the process aborted at exit -- "double free or
+    // corruption" in the static destructors of librocm_smi64, found with rocgdb in round 4 when tests/test_gpu_configs.py was run on its own)
+    for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD); if (h) break; }
+    if (!h) for (const char *nm : names) { h = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (h) break; }
     if (!h) { g_rccl.err = std::string("dlopen(librccl.so): ") + (dlerror() ? dlerror() : "not found"); return false; }
 #define SYM(field, name) do { g_rccl.field = (decltype(g_rccl.field))dlsym(h, name); if (!g_rccl.field) { g_rccl.err = std::string("librccl.so lacks ") + name; dlclose(h); return false; } } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");

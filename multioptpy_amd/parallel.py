@@ -225,9 +225,9 @@ class ShardedBand:
             b.upload_shard(X[s], E[s], G[s])
         halo_exchange(self.bands)
 
-    def model_hessian(self, element_list, approx_hess_type="fischerd3old"):
+    def model_hessian(self, element_list, approx_hess_type="fischerd3old", coords=None, gradients=None):
         for b in self.bands:
-            b.model_hessian(element_list, approx_hess_type)
+            b.model_hessian(element_list, approx_hess_type, coords=coords, gradients=gradients)      # (whole-band arrays: every shard takes its own images)
 
     def step(self, optimize_num):
         step_multi(self.bands, optimize_num)

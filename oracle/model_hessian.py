@@ -641,8 +641,78 @@ def smooth_eigval(w, alpha=0.1):
     return out
 
 
+def ts_hessian(H):
+    """TransitionStateHessian.create_ts_hessian (ModelHessian/tshess.py:14-40): unless an eigenvalue is below -1e-8 already, the lowest mode
+    behind the leading |lambda| < 1e-8 ones is reflected, P = 1 - 2 v v^T, H' = 0.5 (P H + (P H)^T)."""
+    w, V = np.linalg.eigh(H)
+    if np.any(w < -1e-8):
+        return H
+    count = 0
+    for lam in w:
+        if abs(lam) < 1e-8:
+            count += 1
+        else:
+            break
+    v = V[:, count].reshape(-1, 1)
+    P = np.eye(len(H)) - 2.0 * v @ v.T
+    PH = P @ H
+    return 0.5 * (PH + PH.T)
+
+
+# Pauling electronegativities of shortrange.py:160-172 (anything else: 2.0)
+_PAULING = dict(H=2.20, He=0.00, Li=0.98, Be=1.57, B=2.04, C=2.55, N=3.04, O=3.44, F=3.98, Ne=0.00, Na=0.93, Mg=1.31, Al=1.61, Si=1.90, P=2.19,
+                S=2.58, Cl=3.16, Ar=0.00, K=0.82, Ca=1.00, Sc=1.36, Ti=1.54, V=1.63, Cr=1.66, Mn=1.55, Fe=1.83, Co=1.88, Ni=1.91, Cu=1.90, Zn=1.65,
+                Ga=1.81, Ge=2.01, As=2.18, Se=2.55, Br=2.96, Kr=0.00)
+
+
+def short_range_correction(coord, element_list, base_hessian, omega=0.2, cx_sr=0.78, scaling_factor=0.5, cutoff=15.0):
+    """ShortRangeCorrectionHessian.main (ModelHessian/shortrange.py:311-346): radial pair terms of q_i q_j cx s (1 - erf(omega r)) / r over the
+    non-bonded pairs (1.1 x covalent radii, bond_connectivity.py:24-40) within the cut-off (:215-284), TR/rot projection of the correction
+    alone (:303), base + correction symmetrised (:305-307), nan_to_num (:339)."""
+    from scipy.special import erf
+    from . import projection as pj
+    coord = np.asarray(coord, dtype=float).reshape(-1, 3)
+    N = len(coord)
+    cov = element_params(element_list)["cov"]
+    bonded = connect_matrix(coord, cov, 1.1)
+    en = [_PAULING.get(str(e), 2.0) for e in element_list]
+    avg = sum(en) / len(en)
+    q = np.array([0.2 * (avg - v) for v in en])
+    rsp = np.sqrt(np.pi)
+    C = np.zeros((3 * N, 3 * N))
+    for i in range(N):
+        for j in range(i + 1, N):
+            if bonded[i, j]:
+                continue
+            rv = coord[j] - coord[i]
+            r = np.linalg.norm(rv)
+            if r > cutoff:
+                continue
+            u = rv / r
+            if r < 1e-10:
+                d1, d2 = -2 * omega ** 3 / (3 * rsp), 0.0
+            else:
+                ef = erf(omega * r)
+                d1 = 2 * omega * np.exp(-(omega * r) ** 2) / (rsp * r) + (ef - 1.0) / r ** 2
+                exf = np.exp(-(omega * r) ** 2) / rsp
+                d2 = 2 * (2 * ef - 1) / r ** 3 + 4 * omega * exf / r ** 2 + 2 * omega ** 3 * exf
+            ro = np.outer(u, u)
+            blk = q[i] * q[j] * cx_sr * scaling_factor * (d2 * ro + d1 / r * (np.eye(3) - ro))
+            C[3 * i:3 * i + 3, 3 * i:3 * i + 3] += blk
+            C[3 * j:3 * j + 3, 3 * j:3 * j + 3] += blk
+            C[3 * i:3 * i + 3, 3 * j:3 * j + 3] -= blk
+            C[3 * j:3 * j + 3, 3 * i:3 * i + 3] -= blk
+    C = pj.project_hessian_trrot(C, coord)
+    H = np.asarray(base_hessian, dtype=float) + C
+    return np.nan_to_num(0.5 * (H + H.T), nan=0.0)
+
+
 def approx_hessian(coord, element_list, cart_gradient=None, approx_hess_type="fischerd3old"):
     H = _approx_hessian_model(coord, element_list, cart_gradient, approx_hess_type)
+    if "ts" in approx_hess_type.lower():                    # approx_hessian.py:95-98
+        H = ts_hessian(H)
+    if "sr" in approx_hess_type.lower():                    # approx_hessian.py:100-102
+        H = short_range_correction(coord, element_list, H)
     if "clip" in approx_hess_type.lower():                  # approx_hessian.py:104-110
         w, V = np.linalg.eigh(H)
         H = V @ np.diag(smooth_eigval(w)) @ V.T

@@ -1082,6 +1082,29 @@ def g10d_ts_modifier():
     print("G10d:", len(out["tags"]), "geometries")
 
 
+def g10e_sr_modifier():
+    """G10e: the `sr` modifier of ApproxHessian.main (approx_hessian.py:100-102 -> ModelHessian/shortrange.py) and modifier combinations in the
+    reference's order ts -> sr -> clip, through the dispatcher by name, on G10's geometries."""
+    from multioptpy.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(HERE, "g10_model_hessian.npz"))
+    names = ["fischerd3old_sr", "schlegel_sr_clip", "fischer_ts_sr", "morse_ts_clip", "lindh2007d3_sr", "fischerd3_ts_sr_clip"]
+    out = {"tags": z["tags"], "names": np.array(names)}
+    rng = np.random.default_rng(211)
+    for tag in z["tags"]:
+        x, elems = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]]
+        g = rng.normal(0.0, 0.02, x.shape)
+        out[tag + "_x"], out[tag + "_elems"], out[tag + "_g"] = x, z[tag + "_elems"], g
+        for name in names:
+            try:
+                with quiet():
+                    Hm = ApproxHessian().main(x.copy(), list(elems), g.copy(), approx_hess_type=name)
+                out[f"{tag}_H_{name}"] = np.array(Hm)
+            except IndexError:                                # (`ts` on a model Hessian without a non-zero mode, see G10d)
+                out[f"{tag}_H_{name}"] = np.zeros(0)
+    np.savez_compressed(os.path.join(HERE, "g10e_sr_modifier.npz"), **out)
+    print("G10e:", len(out["tags"]), "geometries x", len(names), "names")
+
+
 def g14b_keep_angle():
     """G14b: StructKeepAnglePotential / StructKeepDihedralAnglePotential (Potential/keep_angle_potential.py, keep_dihedral_angle_potential.py):
     energy, torch.func.jacrev gradient and torch.func.hessian Hessian as Potential/potential.py:127-152 forms them -- ordinary geometries, angles
@@ -1156,7 +1179,7 @@ def g14b_keep_angle():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g10d", "g11", "g12", "g12b", "g13", "g14", "g14b", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g10d", "g10e", "g11", "g12", "g12b", "g13", "g14", "g14b", "g15"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -1179,6 +1202,8 @@ if __name__ == "__main__":
         g14b_keep_angle()
     if "g10d" in which:
         g10d_ts_modifier()
+    if "g10e" in which:
+        g10e_sr_modifier()
     if "g12b" in which:
         g12b_constraint_kinds()
     if "g11" in which:

@@ -452,11 +452,44 @@ def test_model_hessian_ts_modifier_vs_reference():
             assert d < 1e-10 * max(1.0, np.abs(ref).max()), (tag, model, d)
             w = np.linalg.eigvalsh(0.5 * (H + H.T))
             assert w[0] < -1e-8                                       # one reflected mode
-    with pytest.raises(NotImplementedError):
-        ApproxHessian().main(z["co2_x"], ["C", "O", "O"], None, approx_hess_type="fischerd3old_sr")
-    with pytest.raises(NotImplementedError):
-        ApproxHessian().main(z["co2_x"], ["C", "O", "O"], None, approx_hess_type="fischerd3old_ts_clip")
     print("ts modifier on the device vs the reference: worst deviation", worst)
+
+
+def test_model_hessian_sr_modifier_and_modifier_order_vs_reference():
+    """G10e: the `sr` modifier (shortrange.py on the device: mopt_model_hessian_sr) and the combinations of ts / sr / clip in the reference's
+    order (clip behind another modifier: mopt_hessian_clip) against ApproxHessian.main of the reference, single geometries and a batch;
+    a band takes such a name through the host-array path."""
+    from multioptpy_amd.ModelHessian.approx_hessian import ApproxHessian
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g10e_sr_modifier.npz"))
+    worst = 0.0
+    for tag in z["tags"]:
+        x, el, g = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]], z[tag + "_g"]
+        for name in (str(v) for v in z["names"]):
+            ref = z[f"{tag}_H_{name}"]
+            if ref.size == 0:
+                with pytest.raises(IndexError):
+                    ApproxHessian().main(x, el, g, approx_hess_type=name)
+                continue
+            H = ApproxHessian().main(x, el, g, approx_hess_type=name)
+            d = np.abs(H - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, d)
+            assert d < (1e-8 if "ts" in name else 1e-9), (tag, name, d)
+    x, el, g = z["aldol_rxn_x"], [str(e) for e in z["aldol_rxn_elems"]], z["aldol_rxn_g"]
+    x2, g2 = z["aldol_jitter_x"], z["aldol_jitter_g"]
+    Hb = ApproxHessian().batch(np.stack([x, x2]), el, "schlegel_sr_clip", cart_gradients=np.stack([g, g2]))
+    assert np.abs(Hb[0] - z["aldol_rxn_H_schlegel_sr_clip"]).max() < 1e-9 and np.abs(Hb[1] - z["aldol_jitter_H_schlegel_sr_clip"]).max() < 1e-9
+    # a band: the name reaches the resident Hessians through ApproxHessian().batch + set_hessian
+    from multioptpy_amd.band import Band
+    N = len(el)
+    b = Band(3, N)
+    X = np.stack([x, x2, x])
+    b.upload(X, np.zeros(3), np.stack([g, g2, g]))
+    b.model_hessian(el, "fischerd3old_sr", coords=X, gradients=np.stack([g, g2, g]))
+    assert np.abs(b.get_hessian(0) - z["aldol_rxn_H_fischerd3old_sr"]).max() < 1e-9
+    with pytest.raises(NotImplementedError):
+        b.model_hessian(el, "fischerd3old_sr")
+    b.close()
+    print("sr modifier / modifier order on the device vs the reference: worst relative deviation", worst)
 
 
 def test_model_hessian_large_cluster_vs_oracle():

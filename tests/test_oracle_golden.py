@@ -574,6 +574,29 @@ def test_oracle_lindh2007d3_vs_reference():
         assert np.abs(mh.approx_hessian(x, el, g, "lindh2007d3_clip") - z[tag + "_Hclip"]).max() < 1e-12, tag
 
 
+def test_oracle_sr_modifier_and_modifier_order_vs_reference():
+    """G10e: the `sr` modifier (ShortRangeCorrectionHessian.main) and combinations of ts / sr / clip in the reference's order, through the
+    oracle's dispatcher by name, against ApproxHessian.main of the reference."""
+    import os
+    import numpy as np
+    from oracle import model_hessian as mh
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10e_sr_modifier.npz"))
+    worst = 0.0
+    for tag in z["tags"]:
+        x, el, g = z[tag + "_x"], [str(e) for e in z[tag + "_elems"]], z[tag + "_g"]
+        for name in (str(v) for v in z["names"]):
+            if "lindh" in name and len(el) > 15:
+                continue                                    # (the Python quadruple loops: kept to seconds)
+            ref = z[f"{tag}_H_{name}"]
+            if ref.size == 0:
+                continue                                    # (the reference's own IndexError, see G10d)
+            H = mh.approx_hessian(x, el, g, name)
+            d = np.abs(H - ref).max() / max(1.0, np.abs(ref).max())
+            worst = max(worst, d)
+            assert d < (1e-8 if "ts" in name else 1e-10), (tag, name, d)      # (ts: the reflected eigenvector of a near-degenerate pair amplifies 1e-16)
+    print("oracle sr / modifier order vs the reference: worst relative deviation", worst)
+
+
 def _replay_mf(z, tag, make):
     """Feeds the recorded inputs of a G15 trace to an MF_RSIRFO object built by make(method, saddle_order, elems, masses, kw); yields (k, opt, step)."""
     N, so, nst = (int(v) for v in z[tag + "_meta"])
