@@ -147,3 +147,12 @@ def test_band_long_run_identity_start_vs_oracle():
     import test_gpu_configs as t
     worst, _ = t._run_band(8, 40, 12, False)
     print("8 x 40 band, 12 steps from identity: worst deviation", worst)
+
+
+def test_headline_band_thirty_steps_identity_start_vs_oracle():
+    """The headline band (32 x 100, n = 300) over thirty steps from identity Hessians against the oracle: the whole range of the early stop --
+    rank 3 .. ~90 on top of the identity, stop rows 10 .. ~100 -- with the deflation budget of k_tri_persist3 in the loop of a real
+    trajectory (every step's geometry within 1e-8 of the oracle's, which uses LAPACK's full reduction)."""
+    import test_gpu_configs as t
+    worst, _ = t._run_band(32, 100, 30, False)
+    print("32 x 100 band, 30 steps from identity: worst deviation", worst)

@@ -17,8 +17,17 @@ n = int(os.environ.get("N", "300"))
 B = int(os.environ.get("B", "32"))
 reps = int(os.environ.get("REPS", "10"))
 rng = np.random.default_rng(0)
-A = rng.standard_normal((B, n, n))
-A = A + A.transpose(0, 2, 1)
+kind = os.environ.get("KIND", "random")              # random | identity | lowrank:<r> (identity + rank r: the early stop's regime)
+if kind == "identity":
+    A = np.stack([np.eye(n)] * B)
+elif kind.startswith("lowrank:"):
+    r = int(kind.split(":")[1])
+    U = rng.standard_normal((B, n, r)) * 0.1
+    A = np.eye(n)[None] + U @ U.transpose(0, 2, 1)
+else:
+    A = rng.standard_normal((B, n, n))
+    A = A + A.transpose(0, 2, 1)
+A = np.ascontiguousarray(A)
 W = np.empty((B, n))
 V = np.empty_like(A)
 sw = np.zeros(B, dtype=np.int32)
@@ -37,4 +46,4 @@ for name in ("eigh_tridiag", "eigh_bisect", "eigh_invit", "eigh_backtrans", "eig
     lib.mopt_ctx_timing_read(c, name.encode(), C.byref(ms), C.byref(nl))
     out.append(f"{name} {ms.value / reps:.4f}")
 lib.mopt_ctx_timing(c, 0)
-print(f"n={n} B={B} rc={sorted(rcs)}  " + "  ".join(out))
+print(f"n={n} B={B} {kind} rc={sorted(rcs)}  " + "  ".join(out))
