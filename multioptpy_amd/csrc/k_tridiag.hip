@@ -29,6 +29,9 @@
 #ifndef MOPT_P3_DEFL_C
 #define MOPT_P3_DEFL_C 16.0    /* deflation budget: everything dropped by one reduction stays below C n eps max(|d|, |e|) in the Frobenius norm, see k_tri_persist3 */
 #endif
+#ifndef MOPT_P3_XCDPRINT
+#define MOPT_P3_XCDPRINT 0      /* 1: k_tri_persist3 prints the XCD placement of the first two matrices under MOPT_TRI_PROF (a device printf in the start-up distorts the profile) */
+#endif
 #ifndef MOPT_P3_DEFLATE
 #define MOPT_P3_DEFLATE 1      /* early stop of the persistent tridiagonalisation on a diagonal trailing block, see k_tri_persist3 */
 #endif
@@ -1043,7 +1046,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
                 if ((unsigned)(w & 0xF) != myx) same = 0;
             }
             s_xloc = same;
-            if (prof && b < 2) printf("[xcd] matrix %d member %d (workgroup %d): XCC %u, all members on one XCD: %d\n", b, g, lin, myx, same);
+            if (prof && b < 2 && MOPT_P3_XCDPRINT) printf("[xcd] matrix %d member %d (workgroup %d): XCC %u, all members on one XCD: %d\n", b, g, lin, myx, same);
         }
         __syncthreads();
     }
@@ -1464,6 +1467,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
         if (prof) { t1 = wall_clock64(); t_main += t1 - t0; }
         return 1;
     };
+    const long long t_setup = prof ? wall_clock64() - w_start : 0;      // (start-up: LDS clear, XCD handshake, row loads)
     for (; k <= k_last; ++k) {
         if (my_last_row <= k + 1) break;                     // (uniform over the workgroup)
         const int lo3 = k + 1 - 3;                           // a chunk is skipped once it has been dead for three steps
@@ -1532,7 +1536,7 @@ __global__ void __launch_bounds__(64 * NWV) k_tri_persist3(int n, int G, int row
             }
         }
     }
-    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = 0; q[3] = t_main; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; }
+    if (prof && tid == 0) { long long *q = prof + ((size_t)b * G + g) * 8; q[0] = t_poll; q[1] = t_pro; q[2] = t_setup; q[3] = t_main; q[4] = t_bar; q[5] = clock64() - c_start; q[6] = wall_clock64() - w_start; q[7] = nsteps; }
     __syncthreads();
     if (tid == 0 && s_fail) atomicAdd(&fail_[b], TRI_FAIL_TIMEOUT);      // (every s_fail of this kernel is a hand-off that timed out)
     if (defl_at >= 0) return;                                // (stopped early: D, E, TAU of the remaining rows are stored, k_tri_tail finds the deflation word)
@@ -2650,6 +2654,14 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             const double f = 0.01 / (batch * G) / (n - 1);     // 100 MHz ticks -> us per step
             fprintf(stderr, "[tri_prof3] n=%d G=%d per step (wave 0): poll %.2f us, prologue %.2f us, barrier %.2f us, main pass %.2f us; shader clock %.0f MHz\n", n, G,
                     sp * f, sr * f, sb * f, sl * f, 100.0 * (double)h[5] / (double)(h[6] ? h[6] : 1));
+            {
+                // whole-kernel view (wall-clock ticks of 10 ns per member): start-up, steps taken, total -- for runs that stop early
+                double su = 0, st = 0, tot = 0, mx = 0;
+                for (int i = 0; i < batch * G; ++i) { su += h[8 * i + 2]; st += h[8 * i + 7]; tot += h[8 * i + 6]; mx = mx > (double)h[8 * i + 6] ? mx : (double)h[8 * i + 6]; }
+                const double m = 1.0 / (batch * G);
+                fprintf(stderr, "[tri_prof3] per member: start-up %.1f us, %.1f steps, poll %.1f + prologue %.1f + barrier %.1f + main %.1f us in them, total %.1f us (slowest member %.1f us)\n",
+                        su * m * 0.01, st * m, sp * m * 0.01, sr * m * 0.01, sb * m * 0.01, sl * m * 0.01, tot * m * 0.01, mx * 0.01);
+            }
         }
     } else if (persist2) {
         mopt_scope sc(ctx, "eigh_tridiag", 1);
