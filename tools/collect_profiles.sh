@@ -15,17 +15,17 @@ for A in 7 22; do cp $S/bench_single_${A}atoms_general_pipeline.json $D/${TAG}_b
 cp $S/single.txt $D/${TAG}_single_geometry_plugin_classes.txt
 grep -v amdgpu.ids $S/timeline.txt > $D/${TAG}_timeline_32x100.txt
 cp $S/pytest.log $D/${TAG}_gpu_suite.log
-cp $P/stats/*/*_kernel_stats.csv $D/${TAG}_bench_32x100_kernel_stats.csv
+cp "$(ls -t $P/stats/*/*_kernel_stats.csv | head -1)" $D/${TAG}_bench_32x100_kernel_stats.csv      # (newest pass when the profile was repeated)
 cp $P/bench_under_stats.json $D/${TAG}_bench_32x100_under_rocprof.json
 cp $P/summary.txt $D/${TAG}_bench_32x100_summary_with_pmc.txt
-cp $S/stats_64x200/*/*_kernel_stats.csv $D/${TAG}_bench_64x200_kernel_stats.csv
+cp "$(ls -t $S/stats_64x200/*/*_kernel_stats.csv | head -1)" $D/${TAG}_bench_64x200_kernel_stats.csv
 cp $S/bench_64x200_under_stats.json $D/${TAG}_bench_64x200_under_rocprof.json
 python3 - "$TAG" <<'PY'
 import csv, glob, json, sys, os
 tag = sys.argv[1]
 sys.path.insert(0, os.getcwd())
 import bench
-rows = list(csv.DictReader(open(glob.glob(f"gpurun_out/prof_{tag}/stats/*/*_kernel_trace.csv")[0])))
+rows = list(csv.DictReader(open(max(glob.glob(f"gpurun_out/prof_{tag}/stats/*/*_kernel_trace.csv"), key=os.path.getmtime))))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 with open(f"profiles/{tag}_k_tri_persist3_per_launch_us.txt", "w") as fh:
     fh.write("# duration of every k_tri_persist3 launch of the default bench command under rocprofv3 --kernel-trace, in launch order (us); <..., true>: early stop on (identity-start workload), <..., false>: exact-start workload\n")

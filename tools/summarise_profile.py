@@ -39,7 +39,8 @@ for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ns"]):
 
 # whole-run totals of the counter passes (raw FETCH_SIZE is doubled: gfx950 counts wide reads at half their bytes)
 tf = sum(v["fetch"] for v in rows.values()); tw = sum(v["write"] for v in rows.values())
-steps = int(os.environ.get("MOPT_PROFILE_STEPS", "0"))
+# band steps of the run = launches of the band's post kernel (the run also steps the band while it builds its input trajectory)
+steps = int(os.environ.get("MOPT_PROFILE_STEPS", "0")) or rows.get("mopt::k_neb_post", {"n": 0})["n"]
 if steps and (tf or tw):
-    print(f"\nall kernels of the run: FETCH {tf / 1024:.1f} MB raw, WRITE {tw / 1024:.1f} MB; per band step over {steps} steps (warm-up included): "
-          f"2 x FETCH + WRITE = {(2 * tf + tw) / 1024 / steps:.1f} MB")
+    print(f"\nall kernels of the run: FETCH {tf / 1024:.1f} MB raw, WRITE {tw / 1024:.1f} MB; per band step over the {steps} band steps of the run (trajectory "
+          f"generation and warm-up included): 2 x FETCH + WRITE = {(2 * tf + tw) / 1024 / steps:.1f} MB")
