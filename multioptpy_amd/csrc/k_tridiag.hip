@@ -2877,7 +2877,12 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         // work-list driven (k_tri_clusters): lw workgroups per matrix walk its list
         int lw = 2048 / batch;
         lw = lw < 8 ? 8 : (lw > n ? n : lw);
-        for (int pass = 0; pass < 2; ++pass) {
+        // (round 4) With the default split -- blocks of 2 .. small_max rows to the whole-block solvers, every matrix with a larger block to the
+        // divide-and-conquer chain -- inverse iteration only ever sees 1 x 1 blocks: the work list of the Loewdin passes is empty by
+        // construction, and their four launches (empty, but dependent kernels on the main stream: ~8 us each with the launch gap, on a
+        // chain about as long as the whole-block solvers' on the helper stream) are left out.  MOPT_TRI_LOWDIN=1 launches them regardless.
+        const bool invit_blocks = !(small_max >= 2 && (n <= small_max || (dc_min > 0 && dc_min <= small_max))) || tri_env("MOPT_TRI_LOWDIN");
+        for (int pass = 0; pass < (invit_blocks ? 2 : 0); ++pass) {
             hipLaunchKernelGGL(k_tri_lowdin, dim3(lw, batch), dim3(n > 256 ? 1024 : 256), (size_t)n * 8, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT,
                                d_onenrm, d_Vt, d_Z2, small_max, (const int *)d_perm, (const int *)d_info);
             hipLaunchKernelGGL(k_tri_lowdin_copy, dim3(lw, batch), dim3(256), 0, ctx->stream, n, batch, d_bstart, d_bend, d_cstart, d_ncl, d_WT, d_onenrm,
@@ -2895,7 +2900,6 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
             fprintf(stderr, "\n");
         }
     }
-    if (small_max > 0) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join4, 0));      // the small blocks' eigenpairs (side stream)
     if (d_dcflag) {                                          // the divide-and-conquer chain (third helper stream)
         static std::map<const mopt_ctx *, unsigned> epochs;      // (one counter per context; the launcher of a context is not re-entered concurrently)
         unsigned epoch;
@@ -2906,6 +2910,10 @@ int mopt_launch_eigh_tridiag(mopt_ctx *ctx, int n, int batch, double *d_A, doubl
         if (serialized_dispatch() || ctx->join_by_events || (tri_env("MOPT_TRI_DCJOIN") && atoi(tri_env("MOPT_TRI_DCJOIN")) == 1)) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join5, 0));
         else hipLaunchKernelGGL(k_dc_wait, dim3(1), dim3(64), 0, ctx->stream, batch, (const int *)d_dcflag, (const unsigned *)word, epoch, d_fail);
     }
+    // (round 4: behind the join with the D&C chain, not in front of it -- k_dc_wait returns at once on the identity-start path, but as a
+    // kernel BEHIND this wait it sat between the whole-block solvers, the longest thing after the tridiagonalisation there, and the sort:
+    // one dependent launch, ~10 us, on the critical path of every step; now it runs while the helper stream is still busy)
+    if (small_max > 0) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join4, 0));      // the small blocks' eigenpairs (side stream)
     if (bt_mfma) MOPT_HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the T factors (side stream)
     if (tri_env("MOPT_TRI_INJECT_FAIL")) MOPT_HIP_TRY(ctx, hipMemsetAsync(d_fail, 1, sizeof(int), ctx->stream));   // test hook: matrix 0 fails
     if (tri_env("MOPT_TRI_INJECT_TIMEOUT") && !ctx->tri_no_persist)       // test hook: matrix 0 reports a hand-off time-out on the persistent route
