@@ -374,6 +374,13 @@ int mopt_keep_angle(mopt_ctx *ctx, int kind, int N, const double *X, int nterms,
  * 0-based atom lists (n1 + n2 <= 64), k in hartree / bohr^2, r0 in bohr. */
 int mopt_keep_pot_v2(mopt_ctx *ctx, int N, const double *X, int n1, const int *frag1, int n2, const int *frag2, double k, double r0, double *E, double *grad,
                      double *H);
+/* The well potentials of Potential/switching_potential.py -- one radial well (linear walls outside [a, d], quintic switches on [a, b] and [c, d], zero
+ * between) on: kind 0 WellPotential (:5-67; list1 / list2 = the two fragments, distance of their centroids), 1 WellPotentialWall (:70-135; |x_i[dir]| of every
+ * atom of list1, dir = prm[8] in 0 / 1 / 2), 2 WellPotentialVP (:138-196; |x_i - p|, p = prm[5..7] in bohr), 3 WellPotentialAround (:199-257; list1 = centre
+ * atoms, list2 = target atoms, |x_i - centroid|).  prm[0..3] = a, b, c, d in bohr, prm[4] = wall energy in hartree; 0-based atom lists (n2 = 0 for kinds 1, 2),
+ * n1 + n2 <= 64.  Energy, gradient and Hessian as the reference takes them from torch autograd (Potential/potential.py:127-152).  Host pointers. */
+int mopt_well_pot(mopt_ctx *ctx, int kind, int N, const double *X, int n1, const int *list1, int n2, const int *list2, const double *prm, double *E, double *grad,
+                  double *H);
 
 /* ---- model Hessians ----------------------------------------------------------------
  * ApproxHessian.main (multioptpy/ModelHessian/approx_hessian.py:30-112) dispatches by name; on the device:

@@ -89,6 +89,8 @@ def _proto(lib):
     if hasattr(lib, "mopt_keep_angle"):
         lib.mopt_keep_angle.argtypes = [vp, C.c_int, C.c_int, DP, C.c_int, IP, DP, DP, DP, DP]
         lib.mopt_keep_pot_v2.argtypes = [vp, C.c_int, DP, C.c_int, IP, C.c_int, IP, C.c_double, C.c_double, DP, DP, DP]
+    if hasattr(lib, "mopt_well_pot"):
+        lib.mopt_well_pot.argtypes = [vp, C.c_int, C.c_int, DP, C.c_int, IP, C.c_int, IP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_keep_pot"):
         lib.mopt_keep_pot.argtypes = [vp, C.c_int, DP, C.c_int, IP, DP, DP, DP, DP]
     if hasattr(lib, "mopt_afir"):

@@ -139,6 +139,85 @@ __global__ void __launch_bounds__(256) k_bias_fragment_distance(int N, const dou
     }
 }
 
+// The well potentials of multioptpy/Potential/switching_potential.py (round 4): ONE radial well w(r) -- linear outside [a, d], a quintic switch on
+// [a, b] and [c, d], zero on (b, c) -- applied to
+//   kind 0  WellPotential        (:5-67)     r = |centroid(list 1) - centroid(list 2)|
+//   kind 1  WellPotentialWall    (:70-135)   r = |x_i[dir]| of every atom i of list 1, summed
+//   kind 2  WellPotentialVP      (:138-196)  r = |x_i - p| of every atom i of list 1 (p: a fixed point), summed
+//   kind 3  WellPotentialAround  (:199-257)  r = |x_i - centroid(list 1)| of every atom i of list 2, summed
+// prm: a, b, c, d (bohr), wall energy (hartree), p (3), dir.  The branch of w is chosen on the value of r, its expression differentiated -- what
+// torch does with the reference's if / elif chain.
+__device__ __forceinline__ HD well_fn(HD r, const double *prm) {
+    const double a = prm[0], b = prm[1], c = prm[2], d = prm[3], e0 = prm[4];
+    const double ss = 0.5 / (b - a), si = 1.0 - 0.5 * b / (b - a), ls = 0.5 / (c - d), li = 1.0 - 0.5 * c / (c - d);
+    const HD xs = ss * r + si, xl = ls * r + li;
+    auto quintic = [&](HD x) { const HD x2 = x * x, x3 = x2 * x; return e0 * (2.0 - 20.0 * x3 + 30.0 * (x3 * x) - 12.0 * (x3 * x2)); };
+    if (r.v <= a) return e0 * (2.875 - 3.75 * xs);
+    if (r.v <= b) return quintic(xs);
+    if (r.v < c) return hd_const(0.0);
+    if (r.v < d) return quintic(xl);
+    return e0 * (2.875 - 3.75 * xl);
+}
+
+// One workgroup; variables = the coordinates of the n1 + n2 list entries (as in k_bias_fragment_distance: repeats add up through the atomics).
+__global__ void __launch_bounds__(256) k_bias_well(int kind, int N, const double *__restrict__ x, int n1, int n2, const int *__restrict__ atoms,
+                                                   const double *__restrict__ prm, double *__restrict__ E, double *__restrict__ g, double *__restrict__ H) {
+    const int nv = 3 * (n1 + n2), np_ = nv * (nv + 1) / 2, n = 3 * N;
+    const int dir = (int)prm[8];
+    for (int t = threadIdx.x; t < np_; t += blockDim.x) {
+        int pi = 0, r = t;
+        while (r >= nv - pi) { r -= nv - pi; ++pi; }
+        const int pj = pi + r;
+        auto coord = [&](int a) -> HD3 {
+            const int at = atoms[a];
+            HD q[3];
+            for (int dd = 0; dd < 3; ++dd) { const int var = 3 * a + dd; q[dd] = {x[3 * at + dd], var == pi ? 1.0 : 0.0, var == pj ? 1.0 : 0.0, 0.0}; }
+            return {q[0], q[1], q[2]};
+        };
+        auto centroid = [&](int a0, int cnt) -> HD3 {
+            HD3 c = {hd_const(0.0), hd_const(0.0), hd_const(0.0)};
+            for (int a = a0; a < a0 + cnt; ++a) { const HD3 q = coord(a); c = {c.x + q.x, c.y + q.y, c.z + q.z}; }
+            return scale(c, hd_const(1.0 / cnt));
+        };
+        // (torch.linalg.norm at the zero vector: value 0 with zero derivatives -- a target atom that is its own centre)
+        auto nrm = [&](HD3 v) -> HD { const HD s2 = dot(v, v); return s2.v > 0.0 ? hd_sqrt(s2) : hd_const(0.0); };
+        HD e = hd_const(0.0);
+        // The VALUE of the summed kinds follows the reference's accumulator (switching_potential.py:117-130: `energy = 0.0; energy += term`, the term
+        // of the zero region being a float32 tensor): when the FIRST target lies in the zero region the accumulator is a float32 tensor and every
+        // later in-place add is computed in double and stored in single precision.  Derivatives are not affected (the cast passes them on).
+        double ev = 0.0;
+        bool first = true, f32 = false;
+        auto term = [&](HD r) {
+            const HD w = well_fn(r, prm);
+            e = e + w;
+            if (first) { first = false; f32 = (r.v > prm[1] && r.v < prm[2]); ev = f32 ? (double)(float)w.v : w.v; }
+            else ev = f32 ? (double)(float)(ev + w.v) : ev + w.v;
+        };
+        if (kind == 0) {
+            const HD3 v = centroid(0, n1) - centroid(n1, n2);
+            e = well_fn(nrm(v), prm);
+            ev = e.v;
+        } else if (kind == 1) {
+            for (int a = 0; a < n1; ++a) {
+                const HD3 q = coord(a);
+                const HD comp = dir == 0 ? q.x : (dir == 1 ? q.y : q.z);
+                term(comp.v < 0.0 ? (0.0 - comp) : comp);               // |x|: sign(x) passes, no curvature
+            }
+        } else if (kind == 2) {
+            const HD3 pt = {hd_const(prm[5]), hd_const(prm[6]), hd_const(prm[7])};
+            for (int a = 0; a < n1; ++a) term(nrm(coord(a) - pt));
+        } else {
+            const HD3 cen = centroid(0, n1);
+            for (int a = n1; a < n1 + n2; ++a) term(nrm(coord(a) - cen));
+        }
+        const int row = 3 * atoms[pi / 3] + pi % 3, col = 3 * atoms[pj / 3] + pj % 3;
+        if (t == 0) E[0] = ev;
+        if (pi == pj) atomicAdd(&g[row], e.a);
+        atomicAdd(&H[(size_t)row * n + col], e.c);
+        if (pi != pj) atomicAdd(&H[(size_t)col * n + row], e.c);
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bias_zero(size_t total, double *__restrict__ H, int n, double *__restrict__ g, double *__restrict__ E) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) H[i] = 0.0;
@@ -264,6 +343,48 @@ extern "C" int mopt_keep_pot_v2(mopt_ctx *ctx, int N, const double *X, int n1, c
         mopt_scope sc(ctx, "bias_keep", 2);
         hipLaunchKernelGGL(k_bias_zero, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, nn, (double *)d, n, (double *)(d + o_g), (double *)(d + o_E));
         hipLaunchKernelGGL(k_bias_fragment_distance, dim3(1), dim3(256), 0, ctx->stream, N, (const double *)(d + o_x), n1, n2, (const int *)(d + o_a), k, r0,
+                           (double *)(d + o_E), (double *)(d + o_g), (double *)d);
+    }
+    MOPT_HIP_TRY(ctx, hipGetLastError());
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(E, d + o_E, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(grad, d + o_g, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(H, d, nn * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return MOPT_OK;
+}
+
+// The well potentials of Potential/switching_potential.py: kind 0 WellPotential (list1 / list2: the two fragments), 1 WellPotentialWall (list1: the target atoms;
+// prm[8]: 0 / 1 / 2 = x / y / z), 2 WellPotentialVP (list1: the target atoms; prm[5..7]: the point, bohr), 3 WellPotentialAround (list1: the centre atoms, list2:
+// the target atoms).  prm[0..3]: the four limit distances in bohr, prm[4]: the wall energy in hartree.  0-based atom lists, n1 + n2 <= 64 entries (repeats allowed).
+// Out: E (1), grad (N x 3), H (3N x 3N).  Host pointers.
+extern "C" int mopt_well_pot(mopt_ctx *ctx, int kind, int N, const double *X, int n1, const int *list1, int n2, const int *list2, const double *prm, double *E,
+                             double *grad, double *H) {
+    using namespace mopt;
+    if (!ctx) return MOPT_E_ARG;
+    const bool two = (kind == 0 || kind == 3);
+    if (kind < 0 || kind > 3 || N < 1 || 3 * N > MOPT_MAX_N || n1 < 1 || (two ? n2 < 1 : n2 != 0) || n1 + n2 > 64 || !X || !list1 || (two && !list2) || !prm || !E || !grad || !H) {
+        ctx->err = "mopt_well_pot: bad argument"; return MOPT_E_ARG;
+    }
+    if (!(prm[1] != prm[0]) || !(prm[2] != prm[3])) { ctx->err = "mopt_well_pot: limit distances a = b or c = d"; return MOPT_E_ARG; }
+    std::vector<int> at;
+    for (int a = 0; a < n1; ++a) at.push_back(list1[a]);
+    for (int a = 0; a < n2; ++a) at.push_back(list2[a]);
+    for (int v : at) if (v < 0 || v >= N) { ctx->err = "mopt_well_pot: atom index out of range (0-based)"; return MOPT_E_ARG; }
+    hipSetDevice(ctx->device);
+    const int n = 3 * N;
+    const size_t nn = (size_t)n * n;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t o_g = al(nn * 8), o_E = o_g + al((size_t)n * 8), o_x = o_E + 256, o_a = o_x + al((size_t)n * 8), o_p = o_a + 512;
+    char *d = nullptr;
+    MOPT_HIP_TRY(ctx, hipMalloc((void **)&d, o_p + 256));
+    struct Free { char *p; ~Free() { if (p) hipFree(p); } } guard{d};
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(d + o_x, X, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(d + o_a, at.data(), at.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    MOPT_HIP_TRY(ctx, hipMemcpyAsync(d + o_p, prm, 9 * 8, hipMemcpyHostToDevice, ctx->stream));
+    {
+        mopt_scope sc(ctx, "bias_keep", 2);
+        hipLaunchKernelGGL(k_bias_zero, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, ctx->stream, nn, (double *)d, n, (double *)(d + o_g), (double *)(d + o_E));
+        hipLaunchKernelGGL(k_bias_well, dim3(1), dim3(256), 0, ctx->stream, kind, N, (const double *)(d + o_x), n1, n2, (const int *)(d + o_a), (const double *)(d + o_p),
                            (double *)(d + o_E), (double *)(d + o_g), (double *)d);
     }
     MOPT_HIP_TRY(ctx, hipGetLastError());

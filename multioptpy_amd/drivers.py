@@ -59,7 +59,7 @@ class ConvergenceChecker:
 
 def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, saddle_order=0, NSTEP=300, FC_COUNT=-1,
                   max_trust_radius=None, min_trust_radius=None, quantise=True, record=None, print_flag=False, model_hessian=None,
-                  MFC_COUNT=50, afir=None, keep_pot=None, projection_constraint=None, keep_angle=None, keep_dihedral=None):
+                  MFC_COUNT=50, afir=None, keep_pot=None, projection_constraint=None, keep_angle=None, keep_dihedral=None, bias_potentials=None):
     """Run up to NSTEP optimizer iterations; returns dict(converged, iterations, geometry_bohr, energy).
     projection_constraint: `-pc` as dict(conditions=[...], atoms=[[...], ...], constants=[...]) (interface.py:453-475): a ProjectOutConstrain
     object goes to CalculateMoveVector, whose crsirfo_* keys then build the constrained optimizer (optimizer.py:450-451, optimization.py:1810-1829).
@@ -131,6 +131,11 @@ def optmain_steps(calculator, start_geometry_ang, element_list, opt_method, sadd
                 from .Potential.keep_angle_potential import keep_angle_sum
                 ke, kg, kh = keep_angle_sum(geometry, [p["atoms"] for p in terms], [p["k"] for p in terms], [p["angle"] for p in terms], dihedral=dih)
                 bias_energy, bias_gradient, bias_hessian = bias_energy + ke, bias_gradient + kg, bias_hessian + kh
+        for pot in (bias_potentials or ()):
+            # any further bias term of Potential/potential.py that has a device counterpart (e.g. the well potentials of Potential/switching_potential.py):
+            # an object with calc_energy_gradient_hessian(geometry in bohr) -> (E, grad (N, 3), H (3N, 3N)), summed as potential.py:127-152 sums them
+            ke, kg, kh = pot.calc_energy_gradient_hessian(geometry)
+            bias_energy, bias_gradient, bias_hessian = bias_energy + ke, bias_gradient + kg, bias_hessian + kh
         if it == 0:                                                     # _save_init_geometry (optimization.py:2206-2217)
             centre = tools.calc_center(geometry, element_list)
             pre_geometry = (geometry - centre) - centre
@@ -188,7 +193,7 @@ def make_band(frames_ang, partition):
 
 def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_COUNT=1, fixedges=0, APPLY_CI_NEB=99999,
                   ratio_of_rfo_step=0.5, quantise=True, record=None, device=None, steepest_descent=99999, devices=None,
-                  transport="rccl", model_hessian=None, MFC_COUNT=50, align_distances=0, climbing_image=(999999, 999999), afir=None, keep_pot=None, keep_angle=None, keep_dihedral=None):
+                  transport="rccl", model_hessian=None, MFC_COUNT=50, align_distances=0, climbing_image=(999999, 999999), afir=None, keep_pot=None, keep_angle=None, keep_dihedral=None, bias_potentials=None):
     """Band relaxation as in nebmain: with FC_COUNT != -1 the Hessian-based branch (`-fc`: RFOOptimizer on a BNEB force),
     otherwise the default FIRE optimizer, replaced by steepest descent from iteration `steepest_descent` on (`-sd`,
     neb.py:794-804, 939-948).
@@ -238,7 +243,7 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
         if hessians is not None and rfo_branch:
             optimizer.set_image_hessians(hessians)
         E_raw = E.copy()
-        if afir is not None or keep_pot or keep_angle or keep_dihedral:
+        if afir is not None or keep_pot or keep_angle or keep_dihedral or bias_potentials:
             Bh = []
             for i in range(len(X)):
                 be, bg, bh = 0.0, np.zeros_like(X[i]), np.zeros((3 * X.shape[1], 3 * X.shape[1]))
@@ -256,6 +261,9 @@ def nebmain_steps(engine, frames_ang, element_list, NSTEP=10, partition=5, FC_CO
                         from .Potential.keep_angle_potential import keep_angle_sum
                         e1, g1, h1 = keep_angle_sum(X[i], [p["atoms"] for p in terms], [p["k"] for p in terms], [p["angle"] for p in terms], dihedral=dih)
                         be, bg, bh = be + e1, bg + g1, bh + h1
+                for pot in (bias_potentials or ()):
+                    e1, g1, h1 = pot.calc_energy_gradient_hessian(X[i])
+                    be, bg, bh = be + e1, bg + g1, bh + h1
                 E[i] += be
                 G[i] += bg
                 Bh.append(bh)

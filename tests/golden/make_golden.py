@@ -1105,6 +1105,62 @@ def g10e_sr_modifier():
     print("G10e:", len(out["tags"]), "geometries x", len(names), "names")
 
 
+def g14c_well_potentials():
+    """G14c: the four well potentials of Potential/switching_potential.py (WellPotential, WellPotentialWall, WellPotentialVP, WellPotentialAround): energy,
+    torch.func.jacrev gradient and torch.func.hessian Hessian as Potential/potential.py:127-152 forms them, with the distance in each of the five
+    regions of the well (linear wall below a, quintic on [a, b], zero, quintic on [c, d), linear wall beyond d)."""
+    import torch
+    from multioptpy.Potential.switching_potential import WellPotential, WellPotentialWall, WellPotentialVP, WellPotentialAround
+    rng = np.random.default_rng(1415)
+    N = 7
+    base = rng.normal(0.0, 2.0, (N, 3))
+    lim = [1.0, 2.0, 4.0, 5.5]                                 # angstrom
+    cases_ = []
+    # kind 0: fragment centres at chosen distances (bohr): inside every region
+    for dist in (1.2, 2.9, 5.6, 8.8, 11.5):
+        x = base.copy()
+        f1, f2 = [1, 2, 3], [5, 6]
+        c1 = x[[0, 1, 2]].mean(axis=0); c2 = x[[4, 5]].mean(axis=0)
+        v = c2 - c1
+        x[[4, 5]] += (c1 + v / np.linalg.norm(v) * dist) - c2
+        cases_.append(("well", x, (f1, f2), 120.0, lim, None))
+    cases_.append(("well", base.copy(), ([7], [1, 2, 3, 4]), 60.0, [0.5, 1.0, 1.5, 2.5], None))
+    # kind 1: walls along x / y / z (targets on both sides of the plane)
+    for d_, tg in (("x", [1, 2, 3, 4, 5, 6, 7]), ("y", [2, 4, 6]), ("z", [1, 7])):
+        cases_.append(("wall", base * 1.8, tg, 80.0, lim, d_))
+    # kind 2: a void point; kind 3: around a centre
+    cases_.append(("vp", base * 1.5, [1, 2, 3, 4, 5, 6, 7], 100.0, lim, [0.31, -0.2, 0.45]))
+    cases_.append(("vp", base * 2.5, [2, 5], 40.0, [0.8, 1.1, 3.0, 3.2], [1.0, 1.0, -1.0]))
+    cases_.append(("around", base * 1.7, ([1, 2], [3, 4, 5, 6, 7]), 90.0, lim, None))
+    cases_.append(("around", base * 2.2, ([4], [1, 2, 4, 6]), 30.0, [0.5, 1.5, 4.5, 6.0], None))      # (a target that is also the centre: r = 0)
+    out = {"ncase": np.array(len(cases_))}
+    for ci, (kind, x, atoms, e0, lims, extra) in enumerate(cases_):
+        tag = f"w{ci:02d}"
+        if kind == "well":
+            pot = WellPotential(well_pot_wall_energy=e0, well_pot_fragm_1=atoms[0], well_pot_fragm_2=atoms[1], well_pot_limit_dist=lims)
+            out[tag + "_l1"], out[tag + "_l2"] = np.array(atoms[0]), np.array(atoms[1])
+        elif kind == "wall":
+            pot = WellPotentialWall(wall_well_pot_wall_energy=e0, wall_well_pot_direction=extra, wall_well_pot_limit_dist=lims, wall_well_pot_target=atoms)
+            out[tag + "_l1"], out[tag + "_l2"], out[tag + "_dir"] = np.array(atoms), np.zeros(0, dtype=int), np.array(extra)
+        elif kind == "vp":
+            pot = WellPotentialVP(void_point_well_pot_wall_energy=e0, void_point_well_pot_coordinate=list(extra), void_point_well_pot_limit_dist=lims, void_point_well_pot_target=atoms)
+            out[tag + "_l1"], out[tag + "_l2"], out[tag + "_point"] = np.array(atoms), np.zeros(0, dtype=int), np.array(extra, dtype=float)
+        else:
+            pot = WellPotentialAround(around_well_pot_wall_energy=e0, around_well_pot_center=atoms[0], around_well_pot_limit_dist=lims, around_well_pot_target=atoms[1])
+            out[tag + "_l1"], out[tag + "_l2"] = np.array(atoms[0]), np.array(atoms[1])
+        xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+        with quiet():
+            E = pot.calc_energy(xt, [])
+            g = torch.func.jacrev(pot.calc_energy, argnums=0)(xt, [])
+            H = torch.func.hessian(pot.calc_energy, argnums=0)(xt, [])
+        out[tag + "_kind"], out[tag + "_x"], out[tag + "_e0"], out[tag + "_lim"] = np.array(kind), x, np.array(e0), np.array(lims, dtype=float)
+        out[tag + "_E"] = np.array(float(E))
+        out[tag + "_g"] = np.asarray(g.detach().numpy(), dtype=float).reshape(N, 3)
+        out[tag + "_H"] = np.asarray(H.detach().numpy(), dtype=float).reshape(3 * N, 3 * N)
+    np.savez_compressed(os.path.join(HERE, "g14c_well_potentials.npz"), **out)
+    print("G14c:", len(cases_), "cases")
+
+
 def g14b_keep_angle():
     """G14b: StructKeepAnglePotential / StructKeepDihedralAnglePotential (Potential/keep_angle_potential.py, keep_dihedral_angle_potential.py):
     energy, torch.func.jacrev gradient and torch.func.hessian Hessian as Potential/potential.py:127-152 forms them -- ordinary geometries, angles
@@ -1179,7 +1235,7 @@ def g14b_keep_angle():
 
 if __name__ == "__main__":
     load_reference()
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g10d", "g10e", "g11", "g12", "g12b", "g13", "g14", "g14b", "g15"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g6b", "g7", "g8", "g8n", "g9", "g10", "g10b", "g10c", "g10d", "g10e", "g11", "g12", "g12b", "g13", "g14", "g14b", "g14c", "g15"]
     if "g13" in which:
         g13_path_tools()
     if "g1" in which:
@@ -1204,6 +1260,8 @@ if __name__ == "__main__":
         g10d_ts_modifier()
     if "g10e" in which:
         g10e_sr_modifier()
+    if "g14c" in which:
+        g14c_well_potentials()
     if "g12b" in which:
         g12b_constraint_kinds()
     if "g11" in which:

@@ -1049,3 +1049,32 @@ def test_rsprfo_update_rejected_by_spectrum_check():
         os.remove(f)
     # (steps without a pending update -- the first of each run -- stay on the fast paths: equal up to the conditioning, not bit for bit)
     assert np.abs(outs[0] - outs[1]).max() < 1e-3 * np.abs(outs[1]).max()
+
+
+def test_well_potentials_vs_reference():
+    """G14c: WellPotential / WellPotentialWall / WellPotentialVP / WellPotentialAround on the device (mopt_well_pot: the reference's if / elif chain on the
+    distance, the selected expression differentiated in hyper-dual arithmetic; the value with the reference's float32 accumulator) against the reference's
+    torch autograd outputs, every region of the well; and against the oracle's hand-written derivatives on a second geometry."""
+    import test_oracle_golden as tog
+    from multioptpy_amd.Potential.switching_potential import WellPotential, WellPotentialWall, WellPotentialVP, WellPotentialAround
+    from oracle import well_pot
+
+    def dev(kind, x, l1, l2, e0, lim, point, direction):
+        if kind == "well":
+            p = WellPotential(well_pot_wall_energy=e0, well_pot_fragm_1=l1, well_pot_fragm_2=l2, well_pot_limit_dist=lim)
+        elif kind == "wall":
+            p = WellPotentialWall(wall_well_pot_wall_energy=e0, wall_well_pot_direction="xyz"[direction], wall_well_pot_limit_dist=lim, wall_well_pot_target=l1)
+        elif kind == "vp":
+            p = WellPotentialVP(void_point_well_pot_wall_energy=e0, void_point_well_pot_coordinate=list(point), void_point_well_pot_limit_dist=lim, void_point_well_pot_target=l1)
+        else:
+            p = WellPotentialAround(around_well_pot_wall_energy=e0, around_well_pot_center=l1, around_well_pot_limit_dist=lim, around_well_pot_target=l2)
+        return p.calc_energy_gradient_hessian(x)
+    worst = tog._check_g14c(dev, 1e-10)
+    rng = np.random.default_rng(77)
+    x = rng.normal(0.0, 3.0, (12, 3))
+    for kind, l1, l2, pt, d in (("well", [1, 2, 3, 4], [9, 10, 11], None, 0), ("wall", list(range(1, 13)), [], None, 2), ("vp", [2, 4, 6, 8, 10, 12], [], [0.5, -1.5, 2.0], 0),
+                                ("around", [1, 5, 9], [2, 3, 4, 6, 7, 8], None, 0)):
+        a = dev(kind, x, l1, l2, 75.0, [1.0, 1.8, 3.0, 4.2], pt if pt is not None else np.zeros(3), d)
+        b = well_pot.well_potential(kind, x, l1, l2, 75.0, [1.0, 1.8, 3.0, 4.2], pt if pt is not None else np.zeros(3), d)
+        assert abs(a[0] - b[0]) < 1e-12 and np.abs(a[1] - b[1]).max() < 1e-12 and np.abs(a[2] - b[2]).max() < 1e-12, kind
+    print("well potentials on the device vs the reference: worst deviation", worst)

@@ -571,7 +571,7 @@ def test_optmain_driver_vs_reference(tag):
     print("optmain", tag, "worst move-vector deviation from the reference", worst)
 
 
-@pytest.mark.parametrize("kind", ["keep", "afir", "both", "angles"])
+@pytest.mark.parametrize("kind", ["keep", "afir", "both", "angles", "wells"])
 def test_optmain_driver_with_bias_vs_oracle(kind):
     """a23 + f3: the in-memory optmain iteration with bias potentials -- harmonic distance restraints (mopt_keep_pot) and / or the AFIR
     term (mopt_afir): bias energy and gradient added to the calculator's, bias Hessian handed to the optimizer -- against the oracle's
@@ -587,6 +587,14 @@ def test_optmain_driver_with_bias_vs_oracle(kind):
     af = dict(gamma=40.0, fragm_1=[1, 2, 3], fragm_2=[5, 6, 7]) if kind in ("afir", "both") else None
     ka = [dict(atoms=[1, 2, 3], k=0.08, angle=75.0), dict(atoms=[4, 5, 6], k=0.05, angle=110.0)] if kind == "angles" else None
     kd = [dict(atoms=[1, 2, 5, 7], k=0.06, angle=40.0)] if kind == "angles" else None
+    # round 4: the well potentials through the drivers' generic hook (objects with calc_energy_gradient_hessian)
+    wells = []
+    if kind == "wells":
+        from multioptpy_amd.Potential.switching_potential import WellPotential, WellPotentialAround
+        from oracle import well_pot as owp
+        wells = [("well", [1, 2], [6, 7], 150.0, [1.0, 2.0, 3.0, 4.5]), ("around", [1, 2, 3], [4, 5, 6, 7], 80.0, [0.5, 1.0, 2.5, 3.5])]
+        wobj = [WellPotential(well_pot_wall_energy=wells[0][3], well_pot_fragm_1=wells[0][1], well_pot_fragm_2=wells[0][2], well_pot_limit_dist=wells[0][4]),
+                WellPotentialAround(around_well_pot_wall_energy=wells[1][3], around_well_pot_center=wells[1][1], around_well_pot_limit_dist=wells[1][4], around_well_pot_target=wells[1][2])]
 
     def bias(x):
         E, g, H = 0.0, np.zeros((N, 3)), np.zeros((3 * N, 3 * N))
@@ -600,10 +608,14 @@ def test_optmain_driver_with_bias_vs_oracle(kind):
             for p in terms or []:
                 e1, g1, h1 = oka.energy_gradient_hessian(x, [a - 1 for a in p["atoms"]], p["k"], oka.deg2rad_as_reference(p["angle"]), dihedral=dih)
                 E, g, H = E + e1, g + g1, H + h1
+        for wk_, l1, l2, e0, lim in wells:
+            e1, g1, h1 = owp.well_potential(wk_, x, l1, l2, e0, lim)
+            E, g, H = E + e1, g + g1, H + h1
         return E, g, H
 
     ra, rb = [], []
-    drivers.optmain_steps(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=ra, afir=af, keep_pot=kp, keep_angle=ka, keep_dihedral=kd)
+    drivers.optmain_steps(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=ra, afir=af, keep_pot=kp, keep_angle=ka, keep_dihedral=kd,
+                          bias_potentials=wobj if kind == "wells" else None)
     driver.run_optmain(cases.LJCalculator(FC_COUNT=-1, project=pj.project_hessian_trrot), x0, el, "rsirfo_bfgs", 0, 6, -1, record=rb, bias=bias)
     assert len(ra) == len(rb) >= 3
     worst = 0.0

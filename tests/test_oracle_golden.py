@@ -597,6 +597,35 @@ def test_oracle_sr_modifier_and_modifier_order_vs_reference():
     print("oracle sr / modifier order vs the reference: worst relative deviation", worst)
 
 
+def _check_g14c(fn, tol):
+    """fn(kind, x, list1, list2, wall energy kJ/mol, limits angstrom, point, direction) -> (E, g, H) against G14c (the reference's torch autograd outputs)."""
+    import os
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g14c_well_potentials.npz"))
+    worst = 0.0
+    for i in range(int(z["ncase"])):
+        tag = f"w{i:02d}"
+        kind = str(z[tag + "_kind"])
+        point = z[tag + "_point"] if (tag + "_point") in z.files else np.zeros(3)
+        direction = {"x": 0, "y": 1, "z": 2}[str(z[tag + "_dir"])] if (tag + "_dir") in z.files else 0
+        E, g, H = fn(kind, z[tag + "_x"], [int(a) for a in z[tag + "_l1"]], [int(a) for a in z[tag + "_l2"]], float(z[tag + "_e0"]), list(z[tag + "_lim"]), point, direction)
+        refH = z[tag + "_H"]
+        sc = max(1.0, np.abs(refH).max())
+        assert abs(E - float(z[tag + "_E"])) < tol * max(1.0, abs(float(z[tag + "_E"]))), (tag, kind, E, float(z[tag + "_E"]))
+        assert np.abs(g - z[tag + "_g"]).max() < tol * sc, (tag, kind, np.abs(g - z[tag + "_g"]).max())
+        assert np.abs(H - refH).max() < tol * sc, (tag, kind, np.abs(H - refH).max())
+        worst = max(worst, np.abs(H - refH).max() / sc, np.abs(g - z[tag + "_g"]).max() / sc)
+    return worst
+
+
+def test_g14c_well_potentials_oracle_vs_reference():
+    """G14c: WellPotential / WellPotentialWall / WellPotentialVP / WellPotentialAround -- the oracle's hand-written radial derivatives against the
+    reference's torch.func.jacrev / hessian outputs, every region of the well."""
+    from oracle import well_pot
+    worst = _check_g14c(well_pot.well_potential, 1e-10)
+    print("oracle well potentials vs the reference: worst deviation", worst)
+
+
 def _replay_mf(z, tag, make):
     """Feeds the recorded inputs of a G15 trace to an MF_RSIRFO object built by make(method, saddle_order, elems, masses, kw); yields (k, opt, step)."""
     N, so, nst = (int(v) for v in z[tag + "_meta"])
