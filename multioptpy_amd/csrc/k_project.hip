@@ -36,7 +36,7 @@ __device__ inline void centre_of(int n, const double *x, double *red, double &cx
 // Q out: [b][6][n] (rows beyond the kept count are zero).  dynamic LDS: 12 * n doubles.
 __global__ void __launch_bounds__(256) k_trrot_basis(int n, const double *__restrict__ X, double *__restrict__ Q) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double red[6 * 16];
+    __shared__ double red[9 * 16];
     double *raw = sm;            // [6][n]
     double *bas = sm + 6 * n;    // [6][n]
     const int b = blockIdx.x;
@@ -45,18 +45,43 @@ __global__ void __launch_bounds__(256) k_trrot_basis(int n, const double *__rest
     centre_of(n, x, red, cx, cy, cz);
     build_trrot(n, x, cx, cy, cz, raw, n);
     __syncthreads();
-    int nb = 0;
-    for (int v = 0; v < 6; ++v) {
-        double d[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            double rv = raw[v * n + i];
-            for (int k = 0; k < nb; ++k) d[k] += rv * bas[k * n + i];
+    // Classical Gram-Schmidt in the order of the reference (calc_tools.py:262-290), with the reductions that cannot change a bit taken out
+    // (round 4; the kernel stands between the upload and the fused update on the critical path of a band step: 13 block reductions -> 7):
+    //  * the three translation vectors have disjoint supports: their mutual projections are exact zeros and |t|^2 = N exactly, so they
+    //    are normalised directly -- the same numbers the general loop produces;
+    //  * the projections of the three rotation vectors on the translations depend on nothing computed in between: one reduction of nine sums.
+    int nb = 3;
+    {
+        const double nrm_t = sqrt((double)(n / 3));
+        for (int i = threadIdx.x; i < 3 * n; i += blockDim.x) bas[i] = raw[i] / nrm_t;
+    }
+    __syncthreads();
+    double dA[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            const double rv = raw[(3 + v) * n + i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dA[3 * v + k] += rv * bas[k * n + i];
         }
-        block_sum<6>(d, red);
+    }
+    block_sum<9>(dA, red);
+    for (int v = 3; v < 6; ++v) {
+        const int ne = nb - 3;                               // rotation vectors kept so far (uniform)
+        double dx[2] = {0, 0};
+        if (ne > 0) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const double rv = raw[v * n + i];
+                for (int k = 0; k < ne; ++k) dx[k] += rv * bas[(3 + k) * n + i];
+            }
+            block_sum<2>(dx, red);
+        }
         double nn = 0.0;
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             double wv = raw[v * n + i];
-            for (int k = 0; k < nb; ++k) wv -= d[k] * bas[k * n + i];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wv -= dA[3 * (v - 3) + k] * bas[k * n + i];
+            for (int k = 0; k < ne; ++k) wv -= dx[k] * bas[(3 + k) * n + i];
             bas[nb * n + i] = wv;       // tentative
             nn += wv * wv;
         }
