@@ -91,29 +91,27 @@ __global__ void __launch_bounds__(512) k_neb_post(int I, int N, int first, int o
     const double *g0 = G + (size_t)i * n;
     const double *f0 = F + (size_t)i * n;
     const double *rs = rfo_step + (size_t)loc * n;
-    // ---- FIRE global switch: sum over ALL images of pre_velocity . force (fire_neb.py:60-65)
+    // ---- FIRE global switch: sum over ALL images of pre_velocity . force (fire_neb.py:60-65), and |rfo step|^2 for the step limit
+    // (rfo_neb.py:76-83) -- independent sums, one reduction round (round 4)
     double dotp = 0.0;
+    double v2[2] = {0.0, 0.0};
+    const bool own_dot = (optimize_num != 0 && have_prev && !dots);
+    if (own_dot) for (size_t k = threadIdx.x; k < (size_t)I * n; k += blockDim.x) v2[0] += pF[k] * F[k];
+    for (int k = threadIdx.x; k < n; k += blockDim.x) v2[1] += rs[k] * rs[k];
+    block_sum<2>(v2, red);
     if (optimize_num != 0 && have_prev) {
         if (dots) {
             // image-sharded band: every rank contributed the sum over its own images (k_band_dot), exchanged by comm.hip;
             // summed here in rank order on every rank -- the same number everywhere, whatever the transport
             for (int r = 0; r < ndots; ++r) dotp += dots[r];
-        } else {
-            double a = 0.0;
-            for (size_t k = threadIdx.x; k < (size_t)I * n; k += blockDim.x) a += pF[k] * F[k];
-            dotp = block_sum1(a, red);
-        }
+        } else dotp = v2[0];
     }
     const bool keep = (optimize_num > 0 && dotp > 0.0 && have_prev);
     // a fresh FIREOptimizer every step (rfo_neb.py:187): dt = 0.5, a = 0.1, n_reset = 0 (never > N_accelerate)
     const double fa = 0.1;
     const double dt = keep ? 0.5 : 0.5 * 0.5;
-    // ---- step limit on the RFO move (rfo_neb.py:76-83)
-    double v6[6] = {0, 0, 0, 0, 0, 0};
-    for (int k = threadIdx.x; k < n; k += blockDim.x) v6[0] += rs[k] * rs[k];
-    block_sum<6>(v6, red);
     {
-        const double nrm = sqrt(v6[0]);
+        const double nrm = sqrt(v2[1]);
         const double lim = is_end ? 0.2 : 0.1;
         for (int k = threadIdx.x; k < n; k += blockDim.x) dl[k] = (nrm > 1e-8) ? rs[k] / nrm * fmin(lim, nrm) : rs[k];
     }
